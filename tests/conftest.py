@@ -1,0 +1,43 @@
+"""Shared pytest configuration.
+
+* ``gpu`` marker: tests that need a real MI355X (run with ``-m gpu`` on the GPU box).
+  Everything else runs on CPU (``-m "not gpu"``).
+* The oracle (``oracle/``) is test infrastructure: tests may import it, the product
+  package ``rlaopt_amd`` never does.
+"""
+
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+# reference tolerances: tests/kernels/test_standard.py:102-105,
+# tests/preconditioners/test_nystrom.py:69-72
+TOL = {
+    torch.float32: dict(rtol=1e-4, atol=1e-4),
+    torch.float64: dict(rtol=1e-8, atol=1e-8),
+}
+DTYPES = {"f32": torch.float32, "f64": torch.float64}
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (HIP kernels execute)")
+
+
+def load_golden(name: str) -> dict:
+    """Load tests/golden/<name>.npz as a dict of torch tensors (CPU)."""
+    with np.load(os.path.join(GOLDEN_DIR, name + ".npz")) as z:
+        return {k: torch.from_numpy(np.array(z[k])) for k in z.files}
+
+
+@pytest.fixture(params=["f32", "f64"])
+def prec(request):
+    return request.param
