@@ -1,0 +1,169 @@
+/*
+ * rk.h - C ABI of librk_hip.so: the MI355X (gfx950) hot path of a randomized-
+ * preconditioned Krylov engine, as a drop-in behind rlaopt's LinOp / Preconditioner /
+ * Solver protocol (see INTEGRATION.md for the reference-side ctypes binding).
+ *
+ * Conventions
+ *   - All matrix pointers are DEVICE pointers (e.g. torch `tensor.data_ptr()`), row-major,
+ *     with explicit leading dimensions counted in ELEMENTS.  No torch types cross the ABI.
+ *   - `dtype`: RK_F32 or RK_F64 selects the arithmetic type of every matrix argument
+ *     unless a parameter says otherwise.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *   - Every entry point returns 0 on success and a negative rk_status otherwise; it never
+ *     throws and never synchronises the device.  `rk_last_error()` returns a thread-local
+ *     message for the last failure on the calling thread.
+ *   - The library owns no user memory.  Kernels that need scratch take a caller-provided
+ *     `ws` buffer whose size is returned by the matching `*_ws_bytes` query.
+ *
+ * Reference citations are paths under the upstream repository (udellgroup/rlaopt @
+ * 2025-05-16); SURVEY.md section 8 row ids in brackets.
+ */
+#ifndef RK_H_
+#define RK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { RK_F32 = 0, RK_F64 = 1 } rk_dtype;
+
+typedef enum {
+    RK_RBF = 0,      /* exp(-sum(((x-y)/l)^2)/2)                rlaopt/kernels/standard.py:46-52 */
+    RK_LAPLACE = 1,  /* exp(-sum(|x-y|/l))                       rlaopt/kernels/standard.py:55-61 */
+    RK_MATERN12 = 2, /* exp(-D), D = sqrt(sum(((x-y)/l)^2))      rlaopt/kernels/standard.py:64-69 */
+    RK_MATERN32 = 3, /* (1+sqrt3 D) exp(-sqrt3 D)                rlaopt/kernels/standard.py:72-77 */
+    RK_MATERN52 = 4  /* (1+sqrt5 D+5/3 D^2) exp(-sqrt5 D)        rlaopt/kernels/standard.py:80-85 */
+} rk_kernel_kind;
+
+typedef enum {
+    RK_OK = 0,
+    RK_ERR_INVALID = -1, /* bad argument (null pointer, size, alignment, unsupported k)  */
+    RK_ERR_LAUNCH = -2,  /* HIP reported an error at launch                               */
+    RK_ERR_WORKSPACE = -3 /* caller workspace too small                                   */
+} rk_status;
+
+/* Thread-local description of the last error on this thread ("" if none). */
+const char* rk_last_error(void);
+/* ABI version (bumped on any signature change). */
+int rk_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Kernel matrices  [a1-a4]
+ *
+ * Entry K[i][j] = scale * kappa(X1[row1(i)], X2[row2(j)]) with row1(i) = idx1 ? idx1[i] : i
+ * (same for row2).  The lengthscale is `ell_scalar` unless `ell_vec` (device, length d,
+ * same dtype) is non-NULL (rlaopt/kernels/configs.py:14,50-60).  idx arrays are device
+ * int64 (the `blk` tensors of rlaopt/kernels/base.py:104-128).
+ * ---------------------------------------------------------------------------------- */
+
+/* Dense block K (n1 x n2, leading dim ldk) written to HBM: the "materialised shard" that
+ * the HBM-bound product rk_matmat_skinny streams.  Replaces the symbolic LazyTensor of
+ * rlaopt/kernels/base.py:88-101 and the per-worker cache of base.py:183-204. */
+int rk_kernel_materialize(int dtype, int kind,
+                          const void* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
+                          const void* X2, int64_t n2, int64_t ldx2, const int64_t* idx2,
+                          int64_t d, double ell_scalar, const void* ell_vec, double scale,
+                          void* K, int64_t ldk, void* stream);
+
+/* Fused matrix-free product Y (n1 x k) = scale * K(X1[idx1], X2[idx2]) @ V (n2 x k),
+ * 1 <= k <= 16; K is never written.  Replaces `LazyTensor @ x` of
+ * rlaopt/kernels/base.py:43-47,112 and the worker-side products of
+ * rlaopt/kernels/utils.py:10-56 (row / block oracles).  The transpose product is the same
+ * call with (X1, idx1) and (X2, idx2) exchanged.  n1 / n2 count the LOGICAL points (the
+ * idx lengths when idx is given).  If `accumulate` != 0, Y += result. */
+size_t rk_kernel_matmat_ws_bytes(int dtype, int64_t n1, int64_t n2, int64_t k);
+int rk_kernel_matmat(int dtype, int kind,
+                     const void* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
+                     const void* X2, int64_t n2, int64_t ldx2, const int64_t* idx2,
+                     int64_t d, double ell_scalar, const void* ell_vec, double scale,
+                     const void* V, int64_t k, int64_t ldv,
+                     void* Y, int64_t ldy, int accumulate,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * HBM-streaming skinny products  [a3 cached shard product, a6 dense tensor operator,
+ * a9 Nystrom apply, a11 block dots]
+ * ---------------------------------------------------------------------------------- */
+
+/* Y (m x k) = alpha * A (m x n) @ V (n x k) + beta * C (m x k) + diag_shift * V[row0 + i]
+ * for 1 <= k <= 16.  `C` may be NULL when beta == 0 and may alias Y.  The diag_shift term
+ * folds "A @ P + reg * P" (rlaopt/solvers/pcg.py:58, models/linsys.py:97) into the
+ * product when A is the row shard [row0, row0 + m) of a square operator.
+ * The dominant, roofline-graded kernel: algorithmic bytes = (m*n + n*k + m*k)*sizeof. */
+size_t rk_matmat_skinny_ws_bytes(int dtype, int64_t m, int64_t n, int64_t k);
+int rk_matmat_skinny(int dtype, const void* A, int64_t m, int64_t n, int64_t lda,
+                     const void* V, int64_t k, int64_t ldv,
+                     double alpha, double beta, const void* C, int64_t ldc,
+                     double diag_shift, int64_t row0,
+                     void* Y, int64_t ldy, void* ws, size_t ws_bytes, void* stream);
+
+/* Y (n x k) = alpha * A^T @ V + beta * C   with A (m x n) row-major, V (m x k),
+ * 1 <= k <= 16.  Serves `x @ A` / `A.T @ x` on dense operators
+ * (rlaopt/linops/base.py:104-111) and the tall inner products U^T R, P^T AP, R^T Z
+ * (rlaopt/preconditioners/nystrom.py:114, rlaopt/solvers/pcg.py:61,79).
+ * `out_f64` != 0 writes Y as float64 regardless of dtype (partials are always summed in
+ * float64). */
+size_t rk_matmat_skinny_t_ws_bytes(int dtype, int64_t m, int64_t n, int64_t k);
+int rk_matmat_skinny_t(int dtype, const void* A, int64_t m, int64_t n, int64_t lda,
+                       const void* V, int64_t k, int64_t ldv,
+                       double alpha, double beta, const void* C, int64_t ldc,
+                       void* Y, int64_t ldy, int out_f64,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Dense MFMA GEMMs  [a7 sketch apply, a8 Nystrom assembly]
+ * ---------------------------------------------------------------------------------- */
+
+/* C (m x n) = alpha * op(A) (m x kd) @ op(B) (kd x n) + beta * C, row-major, MFMA
+ * (v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64).  transX != 0 means the operand is
+ * stored transposed (A stored kd x m).  Serves Y = A @ Omega (rlaopt/sketches/sketch.py:
+ * 86-95), U = Y @ M and dense `A @ X` with many columns. */
+int rk_gemm(int dtype, int transA, int transB, int64_t m, int64_t n, int64_t kd,
+            double alpha, const void* A, int64_t lda, const void* B, int64_t ldb,
+            double beta, void* C, int64_t ldc, void* stream);
+
+/* C (m x n, FLOAT64) = A^T @ B with A (rows x m), B (rows x n) of `dtype`, accumulated in
+ * float64 on the f64 matrix cores and split over `rows` (deterministic two-stage
+ * reduction).  Serves the Gram-type products Omega^T Y and Y^T Y of the Nystrom assembly
+ * (rlaopt/preconditioners/nystrom.py:82,94-95). */
+size_t rk_gram_tn_ws_bytes(int64_t rows, int64_t m, int64_t n);
+int rk_gram_tn(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb,
+               int64_t rows, int64_t m, int64_t n, double* C, int64_t ldc,
+               void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Block-PCG vector updates  [a11]   (all n x k row-major, k <= 16, coefficient
+ * matrices k x k FLOAT64 on the device so that the loop never synchronises the host)
+ * ---------------------------------------------------------------------------------- */
+
+/* W += P @ alpha ; R -= AP @ alpha            (rlaopt/solvers/pcg.py:64-70) */
+int rk_pcg_update_wr(int dtype, int64_t n, int64_t k, void* W, int64_t ldw, void* R, int64_t ldr,
+                     const void* P, int64_t ldp, const void* AP, int64_t ldap,
+                     const double* alpha, void* stream);
+/* P = Z + P @ beta                            (rlaopt/solvers/pcg.py:82-83) */
+int rk_pcg_update_p(int dtype, int64_t n, int64_t k, void* P, int64_t ldp,
+                    const void* Z, int64_t ldz, const double* beta, void* stream);
+/* X = A^-1 B for k x k A and k x nrhs B (FLOAT64, device), LU with partial pivoting,
+ * k <= 16, nrhs <= 16 (torch.linalg.solve at rlaopt/solvers/pcg.py:61,80). A and B are
+ * not modified; X may alias B. */
+int rk_small_solve(int64_t k, int64_t nrhs, const double* A, const double* B, double* X,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Gaussian test matrices  [a7]
+ * ---------------------------------------------------------------------------------- */
+
+/* out (rows x cols, leading dim ld) = scale * N(0,1), Philox4x32-10 counter RNG +
+ * Box-Muller, reproducible for (seed, offset) independent of launch geometry.  The
+ * device-side replacement for `torch.randn(s, d) / sqrt(s)` in
+ * rlaopt/sketches/gauss.py:46-48. */
+int rk_randn(int dtype, void* out, int64_t rows, int64_t cols, int64_t ld,
+             uint64_t seed, uint64_t offset, double scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RK_H_ */

@@ -1,0 +1,679 @@
+// HBM-streaming skinny products for gfx950 (MI355X).
+//
+//   rk_matmat_skinny    Y = alpha A V + beta C + shift V[row0+i]   (A m x n row-major, k <= 16)
+//   rk_matmat_skinny_t  Y = alpha A^T V + beta C
+//
+// Design (DESIGN.md "Kernels"): these products are HBM-bound (k <= 16 gives <= 8 flop/B
+// against a machine balance of ~26 flop/B), so the only thing that matters is streaming A
+// exactly once with wide coalesced loads and enough bytes in flight per CU.
+//   * one 64-lane wave owns R rows of A and walks a column segment in steps of 64 x 16 B
+//     (1 KiB per row per step, `global_load_dwordx4`), so every row read is a full-line
+//     coalesced burst; the next step's R loads are issued before the current step's FMAs
+//     (explicit register double buffer: 2 x R KiB in flight per wave);
+//   * the matching slice of V is read once per step per wave (1/R of the A traffic, served
+//     by the XCD L2 - V is at most a few MB) and reused across the R rows in registers;
+//   * each lane keeps R x k partial sums; one butterfly (DPP/ds_swizzle shuffles) per wave
+//     at the end of the segment turns them into row sums - no LDS, no atomics;
+//   * columns are cut into S segments so that the grid has >= ~20 rounds of resident waves
+//     (tail < 5 %); per-segment partials are summed in a fixed order by a tiny second
+//     kernel, which also applies the epilogue -> bitwise reproducible results.
+#include "rk_common.h"
+
+namespace rk {
+
+// ------------------------------------------------------------------------------------------
+// Y = A V  (row-streaming)
+// ------------------------------------------------------------------------------------------
+template <typename T, int K, int R, bool VEC>
+__global__ void __launch_bounds__(256)
+skinny_nn_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
+                 const T* __restrict__ V, int64_t ldv, T* __restrict__ part, int64_t seg_cols,
+                 // direct epilogue (used when gridDim.y == 1 and part == nullptr)
+                 T alpha, T beta, const T* __restrict__ C, int64_t ldc, T shift, int64_t row0,
+                 T* __restrict__ Y, int64_t ldy) {
+    using V16 = typename Vec16<T>::type;
+    constexpr int VW = Vec16<T>::N;
+    constexpr int STEP = kWave * VW;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * R;
+    if (r0 >= m) return;  // whole wave leaves; no block-level synchronisation below
+    const int64_t c_lo = (int64_t)blockIdx.y * seg_cols;
+    const int64_t c_hi = (c_lo + seg_cols < n) ? c_lo + seg_cols : n;
+
+    const T* arow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int64_t row = r0 + r;
+        if (row > m - 1) row = m - 1;  // clamp: duplicate reads, never written
+        arow[r] = A + row * lda;
+    }
+    T acc[R][K];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < K; ++c) acc[r][c] = T(0);
+
+    int64_t jb = c_lo;
+    if constexpr (VEC) {
+        V16 cur[R], nxt[R];
+        if (jb + STEP <= c_hi) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                cur[r] = *reinterpret_cast<const V16*>(arow[r] + jb + lane * VW);
+        }
+        for (; jb + STEP <= c_hi; jb += STEP) {
+            const int64_t j = jb + lane * VW;
+            if (jb + 2 * STEP <= c_hi) {  // wave-uniform
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    nxt[r] = *reinterpret_cast<const V16*>(arow[r] + j + STEP);
+            }
+            // V[j .. j+VW) x K: VW*K contiguous elements (ldv == K on this path)
+            T v[VW * K];
+            const V16* vp = reinterpret_cast<const V16*>(V + j * K);
+#pragma unroll
+            for (int t = 0; t < K; ++t) {
+                V16 x = vp[t];
+                const T* xe = reinterpret_cast<const T*>(&x);
+#pragma unroll
+                for (int e = 0; e < VW; ++e) v[t * VW + e] = xe[e];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const T* ae = reinterpret_cast<const T*>(&cur[r]);
+#pragma unroll
+                for (int q = 0; q < VW; ++q)
+#pragma unroll
+                    for (int c = 0; c < K; ++c) acc[r][c] += ae[q] * v[q * K + c];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) cur[r] = nxt[r];
+        }
+    }
+    // scalar path: the ragged tail of the segment, or everything when !VEC
+    for (; jb < c_hi; jb += STEP) {
+        const int64_t j = jb + lane * VW;
+#pragma unroll
+        for (int q = 0; q < VW; ++q) {
+            if (j + q < c_hi) {
+                T v[K];
+#pragma unroll
+                for (int c = 0; c < K; ++c) v[c] = V[(j + q) * ldv + c];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const T a = arow[r][j + q];
+#pragma unroll
+                    for (int c = 0; c < K; ++c) acc[r][c] += a * v[c];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < K; ++c) acc[r][c] = wave_sum(acc[r][c]);
+
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = r0 + r;
+            if (row < m) {
+#pragma unroll
+                for (int c = 0; c < K; ++c) {
+                    if (part != nullptr) {
+                        part[((int64_t)blockIdx.y * m + row) * K + c] = acc[r][c];
+                    } else {
+                        T y = alpha * acc[r][c];
+                        if (beta != T(0)) y += beta * C[row * ldc + c];
+                        if (shift != T(0)) y += shift * V[(row0 + row) * ldv + c];
+                        Y[row * ldy + c] = y;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Y[i][c] = alpha * sum_s part[s][i][c] + beta * C[i][c] + shift * V[row0+i][c]
+template <typename T>
+__global__ void __launch_bounds__(256)
+skinny_nn_finish(const T* __restrict__ part, int S, int64_t m, int K, T alpha, T beta,
+                 const T* __restrict__ C, int64_t ldc, T shift, const T* __restrict__ V,
+                 int64_t ldv, int64_t row0, T* __restrict__ Y, int64_t ldy) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m * K) return;
+    const int64_t i = e / K;
+    const int c = (int)(e - i * K);
+    T s = T(0);
+    for (int t = 0; t < S; ++t) s += part[(int64_t)t * m * K + e];
+    T y = alpha * s;
+    if (beta != T(0)) y += beta * C[i * ldc + c];
+    if (shift != T(0)) y += shift * V[(row0 + i) * ldv + c];
+    Y[i * ldy + c] = y;
+}
+
+// ------------------------------------------------------------------------------------------
+// Y = A^T V  (column-owning lanes, rows streamed)
+// ------------------------------------------------------------------------------------------
+template <typename T, int K, bool VEC>
+__global__ void __launch_bounds__(256)
+skinny_t_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
+                const T* __restrict__ V, int64_t ldv, T* __restrict__ part, int64_t ncc,
+                int64_t seg_rows, int64_t nwork) {
+    using V16 = typename Vec16<T>::type;
+    constexpr int VW = Vec16<T>::N;
+    constexpr int STEP = kWave * VW;
+    constexpr int UNR = 8;
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= nwork) return;
+    const int64_t cc = wid % ncc;
+    const int64_t seg = wid / ncc;
+    const int64_t j = cc * STEP + lane * VW;
+    const int64_t i_lo = seg * seg_rows;
+    const int64_t i_hi = (i_lo + seg_rows < m) ? i_lo + seg_rows : m;
+
+    T acc[VW][K];
+#pragma unroll
+    for (int q = 0; q < VW; ++q)
+#pragma unroll
+        for (int c = 0; c < K; ++c) acc[q][c] = T(0);
+
+    const bool full = VEC && (j + VW <= n);
+    if (full) {
+        int64_t i = i_lo;
+        for (; i + UNR <= i_hi; i += UNR) {
+            V16 a[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+                a[u] = *reinterpret_cast<const V16*>(A + (i + u) * lda + j);
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const T* ae = reinterpret_cast<const T*>(&a[u]);
+#pragma unroll
+                for (int c = 0; c < K; ++c) {
+                    const T v = V[(i + u) * ldv + c];  // wave-uniform -> scalar load
+#pragma unroll
+                    for (int q = 0; q < VW; ++q) acc[q][c] += ae[q] * v;
+                }
+            }
+        }
+        for (; i < i_hi; ++i) {
+            V16 a = *reinterpret_cast<const V16*>(A + i * lda + j);
+            const T* ae = reinterpret_cast<const T*>(&a);
+#pragma unroll
+            for (int c = 0; c < K; ++c) {
+                const T v = V[i * ldv + c];
+#pragma unroll
+                for (int q = 0; q < VW; ++q) acc[q][c] += ae[q] * v;
+            }
+        }
+    } else {
+        for (int64_t i = i_lo; i < i_hi; ++i) {
+#pragma unroll
+            for (int q = 0; q < VW; ++q) {
+                if (j + q < n) {
+                    const T a = A[i * lda + j + q];
+#pragma unroll
+                    for (int c = 0; c < K; ++c) acc[q][c] += a * V[i * ldv + c];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < VW; ++q) {
+        if (j + q < n) {
+#pragma unroll
+            for (int c = 0; c < K; ++c) part[(seg * n + j + q) * K + c] = acc[q][c];
+        }
+    }
+}
+
+// out[e] = alpha * sum_s part[s][e] + beta * C[e]; the S partials are summed in float64 by
+// 4 slices per output, combined in a fixed order through LDS.
+template <typename T, typename TO>
+__global__ void __launch_bounds__(256)
+skinny_t_finish(const T* __restrict__ part, int64_t S, int64_t n, int K, double alpha, double beta,
+                const T* __restrict__ C, int64_t ldc, TO* __restrict__ Y, int64_t ldy) {
+    __shared__ double red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + tx;
+    const int64_t total = n * K;
+    double s = 0.0;
+    if (e < total) {
+        for (int64_t t = ty; t < S; t += 4) s += (double)part[t * total + e];
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && e < total) {
+        s = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
+        const int64_t jrow = e / K;
+        const int c = (int)(e - jrow * K);
+        double y = alpha * s;
+        if (beta != 0.0) y += beta * (double)C[jrow * ldc + c];
+        Y[jrow * ldy + c] = (TO)y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// block-PCG vector updates and the k x k solve
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+pcg_update_wr_kernel(int64_t n, int k, T* __restrict__ W, int64_t ldw, T* __restrict__ R,
+                     int64_t ldr, const T* __restrict__ P, int64_t ldp,
+                     const T* __restrict__ AP, int64_t ldap, const double* __restrict__ alpha) {
+    __shared__ T a[16 * 16];
+    if (threadIdx.x < k * k) a[threadIdx.x] = (T)alpha[threadIdx.x];
+    __syncthreads();
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * k) return;
+    const int64_t i = e / k;
+    const int c = (int)(e - i * k);
+    T dw = T(0), dr = T(0);
+    for (int j = 0; j < k; ++j) {
+        dw += P[i * ldp + j] * a[j * k + c];
+        dr += AP[i * ldap + j] * a[j * k + c];
+    }
+    W[i * ldw + c] += dw;
+    R[i * ldr + c] -= dr;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+pcg_update_p_kernel(int64_t n, int k, T* __restrict__ P, int64_t ldp, const T* __restrict__ Z,
+                    int64_t ldz, const double* __restrict__ beta) {
+    __shared__ T b[16 * 16];
+    if (threadIdx.x < k * k) b[threadIdx.x] = (T)beta[threadIdx.x];
+    __syncthreads();
+    // one thread per ROW: the whole old row of P is needed before any entry is overwritten
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    T oldp[16];
+    for (int j = 0; j < k; ++j) oldp[j] = P[i * ldp + j];
+    for (int c = 0; c < k; ++c) {
+        T s = Z[i * ldz + c];
+        for (int j = 0; j < k; ++j) s += oldp[j] * b[j * k + c];
+        P[i * ldp + c] = s;
+    }
+}
+
+// Gaussian elimination with partial pivoting on the augmented matrix [A | B] in LDS.
+__global__ void __launch_bounds__(512)
+small_solve_kernel(int k, int nrhs, const double* __restrict__ A, const double* __restrict__ B,
+                   double* __restrict__ X) {
+    __shared__ double M[16][33];
+    __shared__ int piv;
+    const int r = threadIdx.x >> 5, c = threadIdx.x & 31;  // 16 x 32 threads
+    const int w = k + nrhs;
+    if (r < k && c < w) M[r][c] = (c < k) ? A[r * k + c] : B[r * nrhs + (c - k)];
+    __syncthreads();
+    for (int p = 0; p < k; ++p) {
+        if (threadIdx.x == 0) {
+            int best = p;
+            double bv = fabs(M[p][p]);
+            for (int q = p + 1; q < k; ++q) {
+                const double v = fabs(M[q][p]);
+                if (v > bv) { bv = v; best = q; }
+            }
+            piv = best;
+        }
+        __syncthreads();
+        const int bp = piv;
+        if (bp != p && r == 0 && c < w) {
+            const double t = M[p][c];
+            M[p][c] = M[bp][c];
+            M[bp][c] = t;
+        }
+        __syncthreads();
+        double f = 0.0, pr = 0.0;
+        const bool act = (r > p && r < k && c > p && c < w);
+        if (act) { f = M[r][p] / M[p][p]; pr = M[p][c]; }
+        __syncthreads();
+        if (act) M[r][c] -= f * pr;
+        __syncthreads();
+    }
+    for (int p = k - 1; p >= 0; --p) {
+        if (r == 0 && c >= k && c < w) M[p][c] /= M[p][p];
+        __syncthreads();
+        if (r < p && c >= k && c < w) M[r][c] -= M[r][p] * M[p][c];
+        __syncthreads();
+    }
+    if (r < k && c >= k && c < w) X[r * nrhs + (c - k)] = M[r][c];
+}
+
+// ------------------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+randn_kernel(T* __restrict__ out, int64_t rows, int64_t cols, int64_t ld, uint64_t seed,
+             uint64_t offset, double scale) {
+    // one Philox call -> 4 uniforms -> 2 Box-Muller pairs -> logical elements 4g .. 4g+3
+    const int64_t total = rows * cols;
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g * 4 >= total) return;
+    uint32_t u[4];
+    philox4x32_10((uint32_t)g, (uint32_t)((uint64_t)g >> 32), (uint32_t)offset,
+                  (uint32_t)(offset >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), u);
+    double z[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const double u1 = ((double)u[2 * h] + 1.0) * (1.0 / 4294967296.0);  // (0, 1]
+        const double u2 = (double)u[2 * h + 1] * (1.0 / 4294967296.0);      // [0, 1)
+        const double rad = sqrt(-2.0 * log(u1));
+        double s, co;
+        sincospi(2.0 * u2, &s, &co);
+        z[2 * h] = rad * co;
+        z[2 * h + 1] = rad * s;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t e = g * 4 + q;
+        if (e < total) {
+            const int64_t i = e / cols;
+            out[i * ld + (e - i * cols)] = (T)(scale * z[q]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side planning + dispatch
+// ------------------------------------------------------------------------------------------
+struct NNPlan {
+    int R;             // rows per wave
+    int64_t S;         // column segments
+    int64_t seg_cols;  // multiple of the wave step
+};
+
+static int rows_per_wave(int64_t k) { return k <= 2 ? 8 : (k <= 4 ? 4 : (k <= 8 ? 2 : 1)); }
+
+static NNPlan plan_nn(int dtype, int64_t m, int64_t n, int64_t k) {
+    const int64_t step = (dtype == RK_F32) ? 256 : 128;
+    NNPlan p;
+    p.R = rows_per_wave(k);
+    const int64_t row_waves = ceil_div(m, p.R);
+    // >= ~80k waves in total (20 rounds of 4096 resident waves) but >= 16 steps per wave
+    int64_t S = ceil_div(81920, row_waves);
+    const int64_t max_S = n / (16 * step) > 0 ? n / (16 * step) : 1;
+    if (S > max_S) S = max_S;
+    if (S < 1) S = 1;
+    p.seg_cols = round_up(ceil_div(n, S), step);
+    p.S = ceil_div(n, p.seg_cols);
+    return p;
+}
+
+template <typename T, int K, int R>
+static void launch_nn(bool vec, dim3 grid, hipStream_t st, const T* A, int64_t m, int64_t n,
+                      int64_t lda, const T* V, int64_t ldv, T* part, int64_t seg_cols, T alpha,
+                      T beta, const T* C, int64_t ldc, T shift, int64_t row0, T* Y, int64_t ldy) {
+    if (vec)
+        hipLaunchKernelGGL((skinny_nn_kernel<T, K, R, true>), grid, dim3(256), 0, st, A, m, n, lda,
+                           V, ldv, part, seg_cols, alpha, beta, C, ldc, shift, row0, Y, ldy);
+    else
+        hipLaunchKernelGGL((skinny_nn_kernel<T, K, R, false>), grid, dim3(256), 0, st, A, m, n,
+                           lda, V, ldv, part, seg_cols, alpha, beta, C, ldc, shift, row0, Y, ldy);
+}
+
+template <typename T>
+static int matmat_skinny_impl(const T* A, int64_t m, int64_t n, int64_t lda, const T* V, int64_t k,
+                              int64_t ldv, double alpha, double beta, const T* C, int64_t ldc,
+                              double shift, int64_t row0, T* Y, int64_t ldy, void* ws,
+                              size_t ws_bytes, hipStream_t st, int dtype) {
+    constexpr int VW = Vec16<T>::N;
+    const NNPlan p = plan_nn(dtype, m, n, k);
+    const bool vec = aligned16(A) && aligned16(V) && (lda % VW == 0) && (ldv == k);
+    T* part = nullptr;
+    if (p.S > 1) {
+        const size_t need = (size_t)p.S * m * k * sizeof(T);
+        if (ws == nullptr || ws_bytes < need) {
+            set_error("rk_matmat_skinny: workspace %zu B < required %zu B", ws_bytes, need);
+            return RK_ERR_WORKSPACE;
+        }
+        part = static_cast<T*>(ws);
+    }
+    dim3 grid((unsigned)ceil_div(ceil_div(m, p.R), 4), (unsigned)p.S);
+#define RK_NN_CASE(KK, RR)                                                                       \
+    case KK:                                                                                     \
+        launch_nn<T, KK, RR>(vec, grid, st, A, m, n, lda, V, ldv, part, p.seg_cols, (T)alpha,   \
+                             (T)beta, C, ldc, (T)shift, row0, Y, ldy);                          \
+        break;
+    switch (k) {
+        RK_NN_CASE(1, 8) RK_NN_CASE(2, 8) RK_NN_CASE(3, 4) RK_NN_CASE(4, 4) RK_NN_CASE(5, 2)
+        RK_NN_CASE(6, 2) RK_NN_CASE(7, 2) RK_NN_CASE(8, 2) RK_NN_CASE(9, 1) RK_NN_CASE(10, 1)
+        RK_NN_CASE(11, 1) RK_NN_CASE(12, 1) RK_NN_CASE(13, 1) RK_NN_CASE(14, 1)
+        RK_NN_CASE(15, 1) RK_NN_CASE(16, 1)
+        default:
+            set_error("rk_matmat_skinny: k=%lld outside [1,16]", (long long)k);
+            return RK_ERR_INVALID;
+    }
+#undef RK_NN_CASE
+    int rc = launch_status("rk_matmat_skinny");
+    if (rc != RK_OK) return rc;
+    if (part != nullptr) {
+        const int64_t total = m * k;
+        hipLaunchKernelGGL((skinny_nn_finish<T>), dim3((unsigned)ceil_div(total, 256)), dim3(256), 0,
+                           st, part, (int)p.S, m, (int)k, (T)alpha, (T)beta, C, ldc, (T)shift, V,
+                           ldv, row0, Y, ldy);
+        rc = launch_status("rk_matmat_skinny(finish)");
+    }
+    return rc;
+}
+
+struct TPlan {
+    int64_t ncc, S, seg_rows;
+};
+
+static TPlan plan_t(int dtype, int64_t m, int64_t n) {
+    const int64_t step = (dtype == RK_F32) ? 256 : 128;
+    TPlan p;
+    p.ncc = ceil_div(n, step);
+    int64_t S = ceil_div(32768, p.ncc);  // ~32k waves
+    const int64_t max_S = ceil_div(m, 128);  // >= 128 rows per wave
+    if (S > max_S) S = max_S;
+    if (S < 1) S = 1;
+    p.seg_rows = ceil_div(m, S);
+    p.S = ceil_div(m, p.seg_rows);
+    return p;
+}
+
+template <typename T>
+static int matmat_skinny_t_impl(const T* A, int64_t m, int64_t n, int64_t lda, const T* V,
+                                int64_t k, int64_t ldv, double alpha, double beta, const T* C,
+                                int64_t ldc, void* Y, int64_t ldy, int out_f64, void* ws,
+                                size_t ws_bytes, hipStream_t st, int dtype) {
+    constexpr int VW = Vec16<T>::N;
+    const TPlan p = plan_t(dtype, m, n);
+    const size_t need = (size_t)p.S * n * k * sizeof(T);
+    if (ws == nullptr || ws_bytes < need) {
+        set_error("rk_matmat_skinny_t: workspace %zu B < required %zu B", ws_bytes, need);
+        return RK_ERR_WORKSPACE;
+    }
+    T* part = static_cast<T*>(ws);
+    const bool vec = aligned16(A) && (lda % VW == 0);
+    const int64_t nwork = p.ncc * p.S;
+    dim3 grid((unsigned)ceil_div(nwork, 4));
+#define RK_T_CASE(KK)                                                                            \
+    case KK:                                                                                     \
+        if (vec)                                                                                 \
+            hipLaunchKernelGGL((skinny_t_kernel<T, KK, true>), grid, dim3(256), 0, st, A, m, n,  \
+                               lda, V, ldv, part, p.ncc, p.seg_rows, nwork);                     \
+        else                                                                                     \
+            hipLaunchKernelGGL((skinny_t_kernel<T, KK, false>), grid, dim3(256), 0, st, A, m, n, \
+                               lda, V, ldv, part, p.ncc, p.seg_rows, nwork);                     \
+        break;
+    switch (k) {
+        RK_T_CASE(1) RK_T_CASE(2) RK_T_CASE(3) RK_T_CASE(4) RK_T_CASE(5) RK_T_CASE(6)
+        RK_T_CASE(7) RK_T_CASE(8) RK_T_CASE(9) RK_T_CASE(10) RK_T_CASE(11) RK_T_CASE(12)
+        RK_T_CASE(13) RK_T_CASE(14) RK_T_CASE(15) RK_T_CASE(16)
+        default:
+            set_error("rk_matmat_skinny_t: k=%lld outside [1,16]", (long long)k);
+            return RK_ERR_INVALID;
+    }
+#undef RK_T_CASE
+    int rc = launch_status("rk_matmat_skinny_t");
+    if (rc != RK_OK) return rc;
+    const int64_t total = n * k;
+    dim3 fgrid((unsigned)ceil_div(total, 64));
+    if (out_f64)
+        hipLaunchKernelGGL((skinny_t_finish<T, double>), fgrid, dim3(256), 0, st, part, p.S, n,
+                           (int)k, alpha, beta, C, ldc, static_cast<double*>(Y), ldy);
+    else
+        hipLaunchKernelGGL((skinny_t_finish<T, T>), fgrid, dim3(256), 0, st, part, p.S, n, (int)k,
+                           alpha, beta, C, ldc, static_cast<T*>(Y), ldy);
+    return launch_status("rk_matmat_skinny_t(finish)");
+}
+
+}  // namespace rk
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+using namespace rk;
+
+extern "C" size_t rk_matmat_skinny_ws_bytes(int dtype, int64_t m, int64_t n, int64_t k) {
+    if (m <= 0 || n <= 0 || k <= 0 || k > 16) return 0;
+    const NNPlan p = plan_nn(dtype, m, n, k);
+    const size_t es = dtype == RK_F32 ? 4 : 8;
+    return p.S > 1 ? (size_t)p.S * m * k * es : 0;
+}
+
+extern "C" int rk_matmat_skinny(int dtype, const void* A, int64_t m, int64_t n, int64_t lda,
+                                const void* V, int64_t k, int64_t ldv, double alpha, double beta,
+                                const void* C, int64_t ldc, double diag_shift, int64_t row0,
+                                void* Y, int64_t ldy, void* ws, size_t ws_bytes, void* stream) {
+    clear_error();
+    RK_REQUIRE(dtype == RK_F32 || dtype == RK_F64, "rk_matmat_skinny: bad dtype %d", dtype);
+    RK_REQUIRE(A && V && Y, "rk_matmat_skinny: null pointer");
+    RK_REQUIRE(m > 0 && n > 0, "rk_matmat_skinny: empty operand (m=%lld n=%lld)", (long long)m,
+               (long long)n);
+    RK_REQUIRE(k >= 1 && k <= 16, "rk_matmat_skinny: k=%lld outside [1,16]", (long long)k);
+    RK_REQUIRE(lda >= n && ldv >= k && ldy >= k, "rk_matmat_skinny: leading dimension too small");
+    RK_REQUIRE(beta == 0.0 || (C != nullptr && ldc >= k), "rk_matmat_skinny: beta != 0 needs C");
+    RK_REQUIRE(row0 >= 0, "rk_matmat_skinny: negative row0");
+    RK_REQUIRE(diag_shift == 0.0 || row0 + m <= n,
+               "rk_matmat_skinny: diag_shift needs rows [row0, row0+m) inside V (n=%lld)",
+               (long long)n);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == RK_F32)
+        return matmat_skinny_impl<float>((const float*)A, m, n, lda, (const float*)V, k, ldv, alpha,
+                                         beta, (const float*)C, ldc, diag_shift, row0, (float*)Y,
+                                         ldy, ws, ws_bytes, st, dtype);
+    return matmat_skinny_impl<double>((const double*)A, m, n, lda, (const double*)V, k, ldv, alpha,
+                                      beta, (const double*)C, ldc, diag_shift, row0, (double*)Y, ldy,
+                                      ws, ws_bytes, st, dtype);
+}
+
+extern "C" size_t rk_matmat_skinny_t_ws_bytes(int dtype, int64_t m, int64_t n, int64_t k) {
+    if (m <= 0 || n <= 0 || k <= 0 || k > 16) return 0;
+    const TPlan p = plan_t(dtype, m, n);
+    const size_t es = dtype == RK_F32 ? 4 : 8;
+    return (size_t)p.S * n * k * es;
+}
+
+extern "C" int rk_matmat_skinny_t(int dtype, const void* A, int64_t m, int64_t n, int64_t lda,
+                                  const void* V, int64_t k, int64_t ldv, double alpha, double beta,
+                                  const void* C, int64_t ldc, void* Y, int64_t ldy, int out_f64,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    clear_error();
+    RK_REQUIRE(dtype == RK_F32 || dtype == RK_F64, "rk_matmat_skinny_t: bad dtype %d", dtype);
+    RK_REQUIRE(A && V && Y, "rk_matmat_skinny_t: null pointer");
+    RK_REQUIRE(m > 0 && n > 0, "rk_matmat_skinny_t: empty operand");
+    RK_REQUIRE(k >= 1 && k <= 16, "rk_matmat_skinny_t: k=%lld outside [1,16]", (long long)k);
+    RK_REQUIRE(lda >= n && ldv >= k && ldy >= k, "rk_matmat_skinny_t: leading dimension too small");
+    RK_REQUIRE(beta == 0.0 || (C != nullptr && ldc >= k), "rk_matmat_skinny_t: beta != 0 needs C");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == RK_F32)
+        return matmat_skinny_t_impl<float>((const float*)A, m, n, lda, (const float*)V, k, ldv,
+                                           alpha, beta, (const float*)C, ldc, Y, ldy, out_f64, ws,
+                                           ws_bytes, st, dtype);
+    return matmat_skinny_t_impl<double>((const double*)A, m, n, lda, (const double*)V, k, ldv, alpha,
+                                        beta, (const double*)C, ldc, Y, ldy, out_f64, ws, ws_bytes,
+                                        st, dtype);
+}
+
+extern "C" int rk_pcg_update_wr(int dtype, int64_t n, int64_t k, void* W, int64_t ldw, void* R,
+                                int64_t ldr, const void* P, int64_t ldp, const void* AP,
+                                int64_t ldap, const double* alpha, void* stream) {
+    clear_error();
+    RK_REQUIRE(dtype == RK_F32 || dtype == RK_F64, "rk_pcg_update_wr: bad dtype %d", dtype);
+    RK_REQUIRE(W && R && P && AP && alpha, "rk_pcg_update_wr: null pointer");
+    RK_REQUIRE(n > 0 && k >= 1 && k <= 16, "rk_pcg_update_wr: bad sizes n=%lld k=%lld",
+               (long long)n, (long long)k);
+    RK_REQUIRE(ldw >= k && ldr >= k && ldp >= k && ldap >= k, "rk_pcg_update_wr: bad ld");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)ceil_div(n * k, 256));
+    if (dtype == RK_F32)
+        hipLaunchKernelGGL((pcg_update_wr_kernel<float>), grid, dim3(256), 0, st, n, (int)k,
+                           (float*)W, ldw, (float*)R, ldr, (const float*)P, ldp, (const float*)AP,
+                           ldap, alpha);
+    else
+        hipLaunchKernelGGL((pcg_update_wr_kernel<double>), grid, dim3(256), 0, st, n, (int)k,
+                           (double*)W, ldw, (double*)R, ldr, (const double*)P, ldp,
+                           (const double*)AP, ldap, alpha);
+    return launch_status("rk_pcg_update_wr");
+}
+
+extern "C" int rk_pcg_update_p(int dtype, int64_t n, int64_t k, void* P, int64_t ldp, const void* Z,
+                               int64_t ldz, const double* beta, void* stream) {
+    clear_error();
+    RK_REQUIRE(dtype == RK_F32 || dtype == RK_F64, "rk_pcg_update_p: bad dtype %d", dtype);
+    RK_REQUIRE(P && Z && beta, "rk_pcg_update_p: null pointer");
+    RK_REQUIRE(n > 0 && k >= 1 && k <= 16, "rk_pcg_update_p: bad sizes");
+    RK_REQUIRE(ldp >= k && ldz >= k, "rk_pcg_update_p: bad ld");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)ceil_div(n, 256));
+    if (dtype == RK_F32)
+        hipLaunchKernelGGL((pcg_update_p_kernel<float>), grid, dim3(256), 0, st, n, (int)k,
+                           (float*)P, ldp, (const float*)Z, ldz, beta);
+    else
+        hipLaunchKernelGGL((pcg_update_p_kernel<double>), grid, dim3(256), 0, st, n, (int)k,
+                           (double*)P, ldp, (const double*)Z, ldz, beta);
+    return launch_status("rk_pcg_update_p");
+}
+
+extern "C" int rk_small_solve(int64_t k, int64_t nrhs, const double* A, const double* B, double* X,
+                              void* stream) {
+    clear_error();
+    RK_REQUIRE(A && B && X, "rk_small_solve: null pointer");
+    RK_REQUIRE(k >= 1 && k <= 16 && nrhs >= 1 && nrhs <= 16, "rk_small_solve: sizes outside [1,16]");
+    hipLaunchKernelGGL(small_solve_kernel, dim3(1), dim3(512), 0, static_cast<hipStream_t>(stream),
+                       (int)k, (int)nrhs, A, B, X);
+    return launch_status("rk_small_solve");
+}
+
+extern "C" int rk_randn(int dtype, void* out, int64_t rows, int64_t cols, int64_t ld, uint64_t seed,
+                        uint64_t offset, double scale, void* stream) {
+    clear_error();
+    RK_REQUIRE(dtype == RK_F32 || dtype == RK_F64, "rk_randn: bad dtype %d", dtype);
+    RK_REQUIRE(out != nullptr, "rk_randn: null pointer");
+    RK_REQUIRE(rows > 0 && cols > 0 && ld >= cols, "rk_randn: bad shape");
+    const int64_t groups = ceil_div(rows * cols, 4);
+    dim3 grid((unsigned)ceil_div(groups, 256));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == RK_F32)
+        hipLaunchKernelGGL((randn_kernel<float>), grid, dim3(256), 0, st, (float*)out, rows, cols, ld,
+                           seed, offset, scale);
+    else
+        hipLaunchKernelGGL((randn_kernel<double>), grid, dim3(256), 0, st, (double*)out, rows, cols,
+                           ld, seed, offset, scale);
+    return launch_status("rk_randn");
+}

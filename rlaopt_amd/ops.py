@@ -1,0 +1,344 @@
+"""Tensor-level entry points of the HIP hot path (thin wrappers over the C ABI).
+
+PyTorch is used for device storage and streams only; every n-length or n x n computation
+goes through ``librk_hip.so``.  All functions require CUDA(=HIP) tensors and raise
+otherwise - there is no CPU fallback in the product.
+
+``get_backend()`` returns the object the host-side classes call.  The product default is
+:class:`HipBackend`.  Tests that exercise the *host logic* (sharding, collectives, loop
+cadence) on CPU install an explicit stand-in with ``use_backend(...)``; nothing in this
+package ever does so by itself.
+"""
+
+from __future__ import annotations
+
+import contextlib
+import math
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.RK_F32, torch.float64: _lib.RK_F64}
+MAX_SKINNY = 16  # widest right-hand side handled by the streaming kernels
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _req(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise RuntimeError(
+                "rlaopt_amd: HIP kernels need tensors on a cuda (ROCm) device; "
+                f"got {type(t).__name__} on {getattr(t, 'device', '?')}. There is no CPU fallback."
+            )
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise ValueError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise ValueError(f"dtype must be float32 or float64, got {t.dtype}") from None
+
+
+def _rowmajor(t):
+    """2-D tensor with unit stride along columns (copy if needed) -> (tensor, ld)."""
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+    return t, max(ld, t.shape[1])
+
+
+def _as2d(v):
+    return (v[:, None], True) if v.ndim == 1 else (v, False)
+
+
+class HipBackend:
+    """The product compute backend: every method is one or two kernel launches."""
+
+    name = "hip"
+
+    def __init__(self):
+        self._lib = _lib.load()
+        self._ws = {}
+
+    # -- scratch -----------------------------------------------------------------------
+    def _workspace(self, device, nbytes):
+        if nbytes == 0:
+            return None, 0
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        buf = self._ws.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+            self._ws[key] = buf
+        return buf, buf.numel()
+
+    # -- kernel matrices ---------------------------------------------------------------
+    def _kernel_common(self, kind, X1, X2, lengthscale, idx1, idx2):
+        dev = _req(X1, X2, idx1, idx2)
+        if X1.dtype != X2.dtype:
+            raise ValueError("X1 and X2 must have the same dtype")
+        if X1.shape[1] != X2.shape[1]:
+            raise ValueError("X1 and X2 must have the same number of features")
+        X1, ld1 = _rowmajor(X1)
+        X2, ld2 = _rowmajor(X2)
+        ell_vec = None
+        ell = 1.0
+        if isinstance(lengthscale, torch.Tensor):
+            ell_vec = lengthscale.to(device=dev, dtype=X1.dtype).contiguous()
+            if ell_vec.numel() != X1.shape[1]:
+                raise ValueError("lengthscale tensor must have one entry per feature")
+        else:
+            ell = float(lengthscale)
+        if idx1 is not None:
+            idx1 = idx1.to(device=dev, dtype=torch.int64).contiguous()
+        if idx2 is not None:
+            idx2 = idx2.to(device=dev, dtype=torch.int64).contiguous()
+        n1 = X1.shape[0] if idx1 is None else idx1.numel()
+        n2 = X2.shape[0] if idx2 is None else idx2.numel()
+        return dev, _lib.KIND_IDS[kind], X1, ld1, X2, ld2, ell, ell_vec, idx1, idx2, n1, n2
+
+    def kernel_materialize(self, kind, X1, X2, lengthscale, scale=1.0, idx1=None, idx2=None, out=None):
+        dev, kid, X1, ld1, X2, ld2, ell, ell_vec, idx1, idx2, n1, n2 = self._kernel_common(
+            kind, X1, X2, lengthscale, idx1, idx2
+        )
+        if out is None:
+            out = torch.empty((n1, n2), dtype=X1.dtype, device=dev)
+        rc = self._lib.rk_kernel_materialize(
+            _dt(X1), kid, _ptr(X1), n1, ld1, _ptr(idx1), _ptr(X2), n2, ld2, _ptr(idx2),
+            X1.shape[1], ell, _ptr(ell_vec), float(scale), _ptr(out), out.stride(0), _stream(dev),
+        )
+        _lib.check(rc, "rk_kernel_materialize")
+        return out
+
+    def kernel_matmat(self, kind, X1, X2, lengthscale, V, scale=1.0, idx1=None, idx2=None):
+        """scale * K(X1[idx1], X2[idx2]) @ V, matrix-free; wide V is processed in
+        16-column groups (each group recomputes the kernel entries)."""
+        dev, kid, X1, ld1, X2, ld2, ell, ell_vec, idx1, idx2, n1, n2 = self._kernel_common(
+            kind, X1, X2, lengthscale, idx1, idx2
+        )
+        _req(V)
+        V2, squeeze = _as2d(V)
+        if V2.shape[0] != n2:
+            raise ValueError(f"V has {V2.shape[0]} rows, operator has {n2} columns")
+        if V2.dtype != X1.dtype:
+            raise ValueError("V must have the dtype of the data")
+        V2, ldv = _rowmajor(V2)
+        k = V2.shape[1]
+        out = torch.empty((n1, k), dtype=X1.dtype, device=dev)
+        for c0 in range(0, k, MAX_SKINNY):
+            kc = min(MAX_SKINNY, k - c0)
+            nbytes = self._lib.rk_kernel_matmat_ws_bytes(_dt(X1), n1, n2, kc)
+            ws, wsn = self._workspace(dev, nbytes)
+            es = V2.element_size()
+            rc = self._lib.rk_kernel_matmat(
+                _dt(X1), kid, _ptr(X1), n1, ld1, _ptr(idx1), _ptr(X2), n2, ld2, _ptr(idx2),
+                X1.shape[1], ell, _ptr(ell_vec), float(scale), V2.data_ptr() + c0 * es, kc, ldv,
+                out.data_ptr() + c0 * es, k, 0, _ptr(ws), wsn, _stream(dev),
+            )
+            _lib.check(rc, "rk_kernel_matmat")
+        return out[:, 0] if squeeze else out
+
+    # -- dense products ----------------------------------------------------------------
+    def matmat(self, A, V, alpha=1.0, beta=0.0, C=None, diag_shift=0.0, row0=0):
+        """alpha * A @ V + beta * C + diag_shift * V[row0 : row0 + m]."""
+        dev = _req(A, V, C)
+        V2, squeeze = _as2d(V)
+        if A.shape[1] != V2.shape[0]:
+            raise ValueError(f"shape mismatch: {tuple(A.shape)} @ {tuple(V2.shape)}")
+        if A.dtype != V2.dtype:
+            raise ValueError("A and V must have the same dtype")
+        A, lda = _rowmajor(A)
+        V2, ldv = _rowmajor(V2)
+        m, n = A.shape
+        k = V2.shape[1]
+        C2 = None
+        if C is not None:
+            C2 = C[:, None] if C.ndim == 1 else C
+            C2, ldc = _rowmajor(C2)
+        out = torch.empty((m, k), dtype=A.dtype, device=dev)
+        if k <= MAX_SKINNY:
+            nbytes = self._lib.rk_matmat_skinny_ws_bytes(_dt(A), m, n, k)
+            ws, wsn = self._workspace(dev, nbytes)
+            rc = self._lib.rk_matmat_skinny(
+                _dt(A), _ptr(A), m, n, lda, _ptr(V2), k, ldv, float(alpha), float(beta),
+                _ptr(C2), (ldc if C2 is not None else k), float(diag_shift), int(row0),
+                _ptr(out), k, _ptr(ws), wsn, _stream(dev),
+            )
+            _lib.check(rc, "rk_matmat_skinny")
+        else:
+            if beta != 0.0:
+                out.copy_(C2)
+            rc = self._lib.rk_gemm(
+                _dt(A), 0, 0, m, k, n, float(alpha), _ptr(A), lda, _ptr(V2), ldv, float(beta),
+                _ptr(out), k, _stream(dev),
+            )
+            _lib.check(rc, "rk_gemm")
+            if diag_shift != 0.0:
+                out.add_(V2[row0 : row0 + m], alpha=float(diag_shift))
+        return out[:, 0] if squeeze else out
+
+    def rmatmat(self, A, V, alpha=1.0, beta=0.0, C=None, out_f64=False):
+        """alpha * A.T @ V + beta * C  (A is m x n, V is m x k)."""
+        dev = _req(A, V, C)
+        V2, squeeze = _as2d(V)
+        if A.shape[0] != V2.shape[0]:
+            raise ValueError(f"shape mismatch: {tuple(A.shape)}.T @ {tuple(V2.shape)}")
+        if A.dtype != V2.dtype:
+            raise ValueError("A and V must have the same dtype")
+        A, lda = _rowmajor(A)
+        V2, ldv = _rowmajor(V2)
+        m, n = A.shape
+        k = V2.shape[1]
+        C2 = None
+        if C is not None:
+            C2 = C[:, None] if C.ndim == 1 else C
+            C2, ldc = _rowmajor(C2)
+        odt = torch.float64 if out_f64 else A.dtype
+        out = torch.empty((n, k), dtype=odt, device=dev)
+        if k <= MAX_SKINNY:
+            nbytes = self._lib.rk_matmat_skinny_t_ws_bytes(_dt(A), m, n, k)
+            ws, wsn = self._workspace(dev, nbytes)
+            rc = self._lib.rk_matmat_skinny_t(
+                _dt(A), _ptr(A), m, n, lda, _ptr(V2), k, ldv, float(alpha), float(beta),
+                _ptr(C2), (ldc if C2 is not None else k), _ptr(out), k, int(out_f64),
+                _ptr(ws), wsn, _stream(dev),
+            )
+            _lib.check(rc, "rk_matmat_skinny_t")
+        else:
+            if out_f64:
+                if beta != 0.0:
+                    raise ValueError("out_f64 with beta != 0 is not supported for wide V")
+                out = self.gram_tn(A, V2)
+                if alpha != 1.0:
+                    out.mul_(alpha)
+            else:
+                if beta != 0.0:
+                    out.copy_(C2)
+                rc = self._lib.rk_gemm(
+                    _dt(A), 1, 0, n, k, m, float(alpha), _ptr(A), lda, _ptr(V2), ldv,
+                    float(beta), _ptr(out), k, _stream(dev),
+                )
+                _lib.check(rc, "rk_gemm")
+        return out[:, 0] if squeeze else out
+
+    def gemm(self, A, B, transA=False, transB=False, alpha=1.0):
+        """alpha * op(A) @ op(B) on the matrix cores."""
+        dev = _req(A, B)
+        if A.dtype != B.dtype:
+            raise ValueError("A and B must have the same dtype")
+        A, lda = _rowmajor(A)
+        B, ldb = _rowmajor(B)
+        m, kd = (A.shape[1], A.shape[0]) if transA else A.shape
+        kb, n = (B.shape[1], B.shape[0]) if transB else B.shape
+        if kd != kb:
+            raise ValueError("inner dimensions differ")
+        out = torch.empty((m, n), dtype=A.dtype, device=dev)
+        rc = self._lib.rk_gemm(
+            _dt(A), int(transA), int(transB), m, n, kd, float(alpha), _ptr(A), lda, _ptr(B), ldb,
+            0.0, _ptr(out), n, _stream(dev),
+        )
+        _lib.check(rc, "rk_gemm")
+        return out
+
+    def gram_tn(self, A, B):
+        """float64 A.T @ B for tall A (rows x m), B (rows x n), f64 accumulation."""
+        dev = _req(A, B)
+        if A.dtype != B.dtype or A.shape[0] != B.shape[0]:
+            raise ValueError("A and B must share dtype and row count")
+        A, lda = _rowmajor(A)
+        B, ldb = _rowmajor(B)
+        rows, m = A.shape
+        n = B.shape[1]
+        out = torch.empty((m, n), dtype=torch.float64, device=dev)
+        ws, wsn = self._workspace(dev, self._lib.rk_gram_tn_ws_bytes(rows, m, n))
+        rc = self._lib.rk_gram_tn(
+            _dt(A), _ptr(A), lda, _ptr(B), ldb, rows, m, n, _ptr(out), n, _ptr(ws), wsn,
+            _stream(dev),
+        )
+        _lib.check(rc, "rk_gram_tn")
+        return out
+
+    # -- block PCG pieces --------------------------------------------------------------
+    def pcg_update_wr(self, W, R, P, AP, alpha):
+        dev = _req(W, R, P, AP, alpha)
+        n, k = W.shape
+        rc = self._lib.rk_pcg_update_wr(
+            _dt(W), n, k, _ptr(W), W.stride(0), _ptr(R), R.stride(0), _ptr(P), P.stride(0),
+            _ptr(AP), AP.stride(0), _ptr(alpha), _stream(dev),
+        )
+        _lib.check(rc, "rk_pcg_update_wr")
+
+    def pcg_update_p(self, P, Z, beta):
+        dev = _req(P, Z, beta)
+        n, k = P.shape
+        rc = self._lib.rk_pcg_update_p(
+            _dt(P), n, k, _ptr(P), P.stride(0), _ptr(Z), Z.stride(0), _ptr(beta), _stream(dev)
+        )
+        _lib.check(rc, "rk_pcg_update_p")
+
+    def small_solve(self, A, B):
+        """float64 device solve A X = B, A (k x k), B (k x nrhs), k, nrhs <= 16."""
+        dev = _req(A, B)
+        if A.dtype != torch.float64 or B.dtype != torch.float64:
+            raise ValueError("small_solve works on float64 coefficient matrices")
+        A = A.contiguous()
+        B = B.contiguous()
+        X = torch.empty_like(B)
+        rc = self._lib.rk_small_solve(A.shape[0], B.shape[1], _ptr(A), _ptr(B), _ptr(X), _stream(dev))
+        _lib.check(rc, "rk_small_solve")
+        return X
+
+    def randn(self, rows, cols, dtype, device, seed, offset=0, scale=1.0):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("rlaopt_amd: randn runs on a cuda (ROCm) device only")
+        out = torch.empty((rows, cols), dtype=dtype, device=device)
+        rc = self._lib.rk_randn(
+            _DT[dtype], _ptr(out), rows, cols, cols, int(seed) & (2**64 - 1),
+            int(offset) & (2**64 - 1), float(scale), _stream(device),
+        )
+        _lib.check(rc, "rk_randn")
+        return out
+
+
+_backend = None
+
+
+def get_backend():
+    """The active compute backend (HipBackend unless a test installed a stand-in)."""
+    global _backend
+    if _backend is None:
+        _backend = HipBackend()  # raises loudly when the extension is missing
+    return _backend
+
+
+@contextlib.contextmanager
+def use_backend(backend):
+    """Install ``backend`` for the duration of a ``with`` block (test infrastructure: lets
+    CPU tests drive the host logic with the oracle; never used by the package itself)."""
+    global _backend
+    prev = _backend
+    _backend = backend
+    try:
+        yield backend
+    finally:
+        _backend = prev
+
+
+def sqrt_int(x):  # tiny helper shared by the sketches
+    return math.sqrt(float(x))

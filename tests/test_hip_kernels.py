@@ -1,0 +1,216 @@
+"""GPU parity of every C-ABI entry point against the oracle / a float64 torch reference.
+Runs on the MI355X box only (``-m gpu``)."""
+
+import pytest
+import torch
+
+from conftest import DTYPES, TOL, load_golden
+from oracle import kernels as ok
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    from rlaopt_amd.ops import get_backend
+
+    return get_backend()
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
+
+
+LIM = {torch.float32: 2e-5, torch.float64: 1e-12}
+
+
+def _ls64(ls):
+    return ls.double() if isinstance(ls, torch.Tensor) else ls
+
+
+@pytest.mark.parametrize("kind", ok.KINDS)
+@pytest.mark.parametrize("ell", ["scalar", "ard"])
+@pytest.mark.parametrize("shape", ["small", "ragged"])
+def test_materialize_matches_reference_closed_form(be, prec, kind, ell, shape):
+    g = load_golden(f"kernels_{prec}")
+    X1, X2 = g[f"{shape}_X1"].to(dev()), g[f"{shape}_X2"].to(dev())
+    ls = 1.0 if ell == "scalar" else g[f"{shape}_ard"].to(dev())
+    K = be.kernel_materialize(kind, X1, X2, ls, scale=2.0)
+    torch.testing.assert_close(K.cpu(), g[f"{shape}_{kind}_{ell}"], **TOL[DTYPES[prec]])
+
+
+@pytest.mark.parametrize("kind", ok.KINDS)
+@pytest.mark.parametrize(
+    "n1,n2,d,k", [(10, 5, 3, 1), (130, 257, 7, 3), (300, 1000, 40, 10), (65, 64, 33, 16), (70, 90, 5, 37)]
+)
+def test_kernel_matmat_and_materialize_vs_oracle(be, prec, kind, n1, n2, d, k):
+    dt = DTYPES[prec]
+    gen = torch.Generator().manual_seed(n1 * 7 + n2)
+    X1 = torch.randn(n1, d, dtype=dt, generator=gen) / d**0.5
+    X2 = torch.randn(n2, d, dtype=dt, generator=gen) / d**0.5
+    V = torch.randn(n2, k, dtype=dt, generator=gen)
+    ard = torch.rand(d, dtype=dt, generator=gen) + 0.5
+    for ls in (0.7, ard):
+        want = ok.kernel_matmat(kind, X1.double(), X2.double(), _ls64(ls), V.double(), 1.5)
+        lsd = ls.to(dev()) if isinstance(ls, torch.Tensor) else ls
+        got = be.kernel_matmat(kind, X1.to(dev()), X2.to(dev()), lsd, V.to(dev()), scale=1.5)
+        assert rel_err(got.cpu(), want) < LIM[dt]
+        Kd = be.kernel_materialize(kind, X1.to(dev()), X2.to(dev()), lsd, scale=1.5)
+        Kw = ok.kernel_matrix(kind, X1.double(), X2.double(), _ls64(ls), 1.5)
+        assert rel_err(Kd.cpu(), Kw) < LIM[dt]
+    # 1-D right-hand side
+    got = be.kernel_matmat(kind, X1.to(dev()), X2.to(dev()), 0.7, V[:, 0].contiguous().to(dev()))
+    want = ok.kernel_matmat(kind, X1.double(), X2.double(), 0.7, V[:, 0].double())
+    assert got.ndim == 1 and rel_err(got.cpu(), want) < LIM[dt]
+
+
+def test_kernel_index_oracles(be, prec):
+    """row oracle K(X[blk], X) and block oracle K(X[blk], X[blk]) gathers (base.py:104-128)."""
+    dt = DTYPES[prec]
+    gen = torch.Generator().manual_seed(3)
+    n, d, k = 500, 9, 4
+    X = torch.randn(n, d, dtype=dt, generator=gen) / 3
+    blk = torch.randperm(n, generator=gen)[:77]
+    V = torch.randn(n, k, dtype=dt, generator=gen)
+    Vb = torch.randn(77, k, dtype=dt, generator=gen)
+    Xd, bd = X.to(dev()), blk.to(dev())
+    for kind in ("rbf", "matern52"):
+        got = be.kernel_matmat(kind, Xd, Xd, 1.0, V.to(dev()), idx1=bd)
+        want = ok.kernel_matmat(kind, X.double(), X.double(), 1.0, V.double(), idx1=blk)
+        assert rel_err(got.cpu(), want) < LIM[dt]
+        got = be.kernel_matmat(kind, Xd, Xd, 1.0, Vb.to(dev()), idx1=bd, idx2=bd)
+        want = ok.kernel_matmat(kind, X.double(), X.double(), 1.0, Vb.double(), idx1=blk, idx2=blk)
+        assert rel_err(got.cpu(), want) < LIM[dt]
+        Kb = be.kernel_materialize(kind, Xd, Xd, 1.0, idx1=bd, idx2=bd)
+        assert rel_err(Kb.cpu(), ok.kernel_matrix(kind, X[blk].double(), X[blk].double(), 1.0)) < LIM[dt]
+
+
+@pytest.mark.parametrize("m,n", [(1, 1), (7, 5), (64, 256), (100, 1000), (257, 4099), (1000, 9000), (3000, 70000)])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 8, 10, 16])
+def test_matmat_skinny(be, prec, m, n, k):
+    dt = DTYPES[prec]
+    gen = torch.Generator().manual_seed(m + n + k)
+    A = torch.randn(m, n, dtype=dt, generator=gen)
+    V = torch.randn(n, k, dtype=dt, generator=gen)
+    C = torch.randn(m, k, dtype=dt, generator=gen)
+    Ad = A.to(dev())
+    got = be.matmat(Ad, V.to(dev()), alpha=-0.5, beta=2.0, C=C.to(dev()))
+    want = -0.5 * (A.double() @ V.double()) + 2.0 * C.double()
+    assert rel_err(got.cpu(), want) < LIM[dt] * 5
+    got = be.matmat(Ad, V.to(dev()))
+    assert rel_err(got.cpu(), A.double() @ V.double()) < LIM[dt] * 5
+    # transpose product, float64 output
+    U = torch.randn(m, k, dtype=dt, generator=gen)
+    got = be.rmatmat(Ad, U.to(dev()), out_f64=True)
+    assert got.dtype == torch.float64
+    assert rel_err(got.cpu(), A.double().T @ U.double()) < LIM[dt] * 5
+    got = be.rmatmat(Ad, U.to(dev()), alpha=2.0)
+    assert got.dtype == dt and rel_err(got.cpu(), 2 * A.double().T @ U.double()) < LIM[dt] * 5
+
+
+def test_matmat_skinny_diag_shift_and_unaligned(be, prec):
+    dt = DTYPES[prec]
+    gen = torch.Generator().manual_seed(5)
+    n, m, row0, k = 999, 301, 200, 3
+    Afull = torch.randn(n, n + 1, dtype=dt, generator=gen)  # odd leading dimension
+    A = Afull[row0 : row0 + m, :n]
+    V = torch.randn(n, k, dtype=dt, generator=gen)
+    Ad = Afull.to(dev())[row0 : row0 + m, :n]  # genuinely strided, unaligned rows on the device
+    got = be.matmat(Ad, V.to(dev()), diag_shift=0.25, row0=row0)
+    want = A.double() @ V.double() + 0.25 * V[row0 : row0 + m].double()
+    assert rel_err(got.cpu(), want) < LIM[dt] * 5
+    got = be.matmat(Ad, V[:, 0].contiguous().to(dev()))
+    assert got.ndim == 1 and rel_err(got.cpu(), A.double() @ V[:, 0].double()) < LIM[dt] * 5
+    got = be.rmatmat(Ad, torch.ones(m, 2, dtype=dt, device=dev()))
+    assert rel_err(got.cpu(), A.double().T @ torch.ones(m, 2, dtype=torch.float64)) < LIM[dt] * 5
+
+
+@pytest.mark.parametrize("m,n,kd", [(128, 128, 16), (200, 96, 50), (1000, 512, 777), (130, 260, 1030), (33, 17, 5)])
+@pytest.mark.parametrize("tA", [False, True])
+@pytest.mark.parametrize("tB", [False, True])
+def test_gemm_mfma(be, prec, m, n, kd, tA, tB):
+    dt = DTYPES[prec]
+    gen = torch.Generator().manual_seed(m * 3 + n + kd)
+    # asymmetric integer-valued operands catch swapped lane maps exactly
+    A = torch.randint(-3, 4, (kd, m) if tA else (m, kd), generator=gen).to(dt)
+    B = torch.randint(-3, 4, (n, kd) if tB else (kd, n), generator=gen).to(dt)
+    got = be.gemm(A.to(dev()), B.to(dev()), transA=tA, transB=tB)
+    want = (A.T if tA else A).double() @ (B.T if tB else B).double()
+    assert torch.equal(got.cpu().double(), want)
+    A = torch.randn(A.shape, dtype=dt, generator=gen)
+    B = torch.randn(B.shape, dtype=dt, generator=gen)
+    got = be.gemm(A.to(dev()), B.to(dev()), transA=tA, transB=tB, alpha=0.5)
+    want = 0.5 * (A.T if tA else A).double() @ (B.T if tB else B).double()
+    assert rel_err(got.cpu(), want) < LIM[dt] * 5
+
+
+def test_matmat_wide_goes_through_gemm(be, prec):
+    dt = DTYPES[prec]
+    gen = torch.Generator().manual_seed(9)
+    A = torch.randn(300, 420, dtype=dt, generator=gen)
+    V = torch.randn(420, 40, dtype=dt, generator=gen)
+    U = torch.randn(300, 40, dtype=dt, generator=gen)
+    assert rel_err(be.matmat(A.to(dev()), V.to(dev())).cpu(), A.double() @ V.double()) < LIM[dt] * 5
+    assert rel_err(be.rmatmat(A.to(dev()), U.to(dev())).cpu(), A.double().T @ U.double()) < LIM[dt] * 5
+    got = be.rmatmat(A.to(dev()), U.to(dev()), out_f64=True)
+    assert got.dtype == torch.float64 and rel_err(got.cpu(), A.double().T @ U.double()) < 1e-13
+
+
+@pytest.mark.parametrize("rows,m,n", [(100, 8, 8), (5000, 64, 48), (20000, 200, 200), (777, 130, 5)])
+def test_gram_tn_float64_accumulation(be, prec, rows, m, n):
+    dt = DTYPES[prec]
+    gen = torch.Generator().manual_seed(rows + m)
+    A = torch.randn(rows, m, dtype=dt, generator=gen)
+    B = torch.randn(rows, n, dtype=dt, generator=gen)
+    got = be.gram_tn(A.to(dev()), B.to(dev()))
+    assert got.dtype == torch.float64
+    assert rel_err(got.cpu(), A.double().T @ B.double()) < 1e-13  # f64 accumulation of exact inputs
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 7, 16])
+def test_pcg_updates_and_small_solve(be, prec, k):
+    dt = DTYPES[prec]
+    gen = torch.Generator().manual_seed(k)
+    n = 1234
+    W, R, P, AP, Z = (torch.randn(n, k, dtype=dt, generator=gen) for _ in range(5))
+    al = torch.randn(k, k, dtype=torch.float64, generator=gen)
+    Wd, Rd, Pd = W.to(dev()), R.to(dev()), P.to(dev())
+    be.pcg_update_wr(Wd, Rd, Pd, AP.to(dev()), al.to(dev()))
+    assert rel_err(Wd.cpu(), W.double() + P.double() @ al) < LIM[dt]
+    assert rel_err(Rd.cpu(), R.double() - AP.double() @ al) < LIM[dt]
+    be.pcg_update_p(Pd, Z.to(dev()), al.to(dev()))
+    assert rel_err(Pd.cpu(), Z.double() + P.double() @ al) < LIM[dt]
+    M = torch.randn(k, k, dtype=torch.float64, generator=gen)
+    M = M @ M.T + 0.1 * torch.eye(k, dtype=torch.float64)
+    M[0], M[k - 1] = M[k - 1].clone(), M[0].clone()  # force pivoting
+    Bm = torch.randn(k, min(k + 1, 16), dtype=torch.float64, generator=gen)
+    X = be.small_solve(M.to(dev()), Bm.to(dev()))
+    assert rel_err(X.cpu(), torch.linalg.solve(M, Bm)) < 1e-10
+
+
+def test_randn_statistics_and_reproducibility(be, prec):
+    dt = DTYPES[prec]
+    a = be.randn(1000, 513, dt, dev(), seed=123, offset=0, scale=2.0)
+    b = be.randn(1000, 513, dt, dev(), seed=123, offset=0, scale=2.0)
+    c = be.randn(1000, 513, dt, dev(), seed=124, offset=0, scale=2.0)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    x = a.double().cpu() / 2.0
+    assert abs(float(x.mean())) < 5e-3 and abs(float(x.std()) - 1) < 5e-3
+    assert abs(float((x**4).mean()) - 3) < 0.05 and torch.isfinite(x).all()
+    assert abs(float((x[0] * x[1]).mean())) < 0.2
+
+
+def test_bad_arguments_raise(be):
+    A = torch.zeros(4, 4, device=dev())
+    with pytest.raises(ValueError):
+        be.matmat(A, torch.zeros(5, 1, device=dev()))
+    with pytest.raises(RuntimeError):
+        be.matmat(A.cpu(), torch.zeros(4, 1))
+    with pytest.raises(ValueError):
+        be.kernel_materialize("rbf", A, A, -1.0)
+    with pytest.raises(ValueError):
+        be.matmat(A.to(torch.float16), torch.zeros(4, 1, device=dev(), dtype=torch.float16))
