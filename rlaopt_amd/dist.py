@@ -1,0 +1,113 @@
+"""Process-group helpers for the row-sharded operator (one process per GPU).
+
+The reference moves every operand and result through ``torch.multiprocessing`` queues with
+host staging (rlaopt/linops/base.py:157-176,202-267).  Here the shards live in separate
+ranks of a ``torch.distributed`` group (backend "nccl" = RCCL over xGMI on the GPUs, "gloo"
+in the CPU tests) and exchange device-resident buffers:
+
+* ROW-mode product  (linops/distributed.py:40-45):  concat      -> all-gather of row blocks
+* COLUMN-mode / transpose product (:46-50, :81-86): sum         -> all-reduce
+* block inner products of PCG / Nystrom:             one fused all-reduce per use
+
+The row partition is the reference's ``torch.chunk(arange(n), p)`` (kernels/base.py:297-302):
+ceil(n/p)-sized blocks, possibly FEWER than p of them; ranks beyond the last block own no
+rows.
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.distributed as td
+
+
+def initialized() -> bool:
+    return td.is_available() and td.is_initialized()
+
+
+def world(group=None) -> tuple[int, int]:
+    """(rank, world_size); (0, 1) when no process group exists."""
+    if not initialized():
+        return 0, 1
+    return td.get_rank(group), td.get_world_size(group)
+
+
+def row_chunks(n: int, parts: int) -> list[tuple[int, int]]:
+    """[lo, hi) of every block of ``torch.chunk(arange(n), parts)``."""
+    if n <= 0 or parts <= 0:
+        raise ValueError("n and parts must be positive")
+    step = -(-n // parts)
+    return [(lo, min(lo + step, n)) for lo in range(0, n, step)]
+
+
+def my_rows(n: int, group=None) -> tuple[int, int]:
+    """This rank's [lo, hi) (empty ``(n, n)`` for a rank past the last block)."""
+    rank, size = world(group)
+    chunks = row_chunks(n, size)
+    return chunks[rank] if rank < len(chunks) else (n, n)
+
+
+def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place sum over ranks (no-op without a group)."""
+    if initialized() and td.get_world_size(group) > 1:
+        td.all_reduce(t, op=td.ReduceOp.SUM, group=group)
+    return t
+
+
+def chunk_sizes(n: int, group=None) -> list[int]:
+    """Rows owned by each rank under ``row_chunks`` (0 for ranks past the last block)."""
+    _, size = world(group)
+    ch = row_chunks(n, size)
+    return [hi - lo for lo, hi in ch] + [0] * (size - len(ch))
+
+
+def all_gather_rows(local: torch.Tensor, sizes, group=None) -> torch.Tensor:
+    """Concatenate per-rank row blocks (``sizes[r]`` rows on rank r; an int ``n`` means the
+    ``row_chunks`` partition of n rows).  Blocks are padded to the tallest one so that a
+    single ``all_gather_into_tensor`` moves everything."""
+    rank, size = world(group)
+    if size == 1:
+        return local
+    if isinstance(sizes, int):
+        sizes = chunk_sizes(sizes, group)
+    if len(sizes) != size:
+        sizes = list(sizes) + [0] * (size - len(sizes))
+    squeeze = local.ndim == 1
+    loc = local[:, None] if squeeze else local
+    if loc.shape[0] != sizes[rank]:
+        raise ValueError(f"rank {rank} holds {loc.shape[0]} rows, partition says {sizes[rank]}")
+    k = loc.shape[1]
+    step = max(sizes)
+    if loc.shape[0] != step:
+        pad = torch.zeros((step, k), dtype=loc.dtype, device=loc.device)
+        pad[: loc.shape[0]] = loc
+        loc = pad
+    out = torch.empty((size * step, k), dtype=loc.dtype, device=loc.device)
+    td.all_gather_into_tensor(out, loc.contiguous(), group=group)
+    total = sum(sizes)
+    if _tail_only(sizes, step):  # padding only behind the last non-empty block: one slice
+        out = out[:total]
+    else:
+        out = torch.cat([out[r * step : r * step + sizes[r]] for r in range(size)], dim=0)
+    return out[:, 0] if squeeze else out
+
+
+def _first_short(sizes, step):
+    for i, s in enumerate(sizes):
+        if s != step:
+            return i
+    return len(sizes)
+
+
+def _tail_only(sizes, step):
+    """True when every block before the first short one is full and all later ones empty."""
+    i = _first_short(sizes, step)
+    return all(s == 0 for s in sizes[i + 1 :])
+
+
+def broadcast_object(obj, src: int = 0, group=None):
+    """Small Python object from ``src`` to every rank (e.g. an RNG seed)."""
+    if not initialized() or td.get_world_size(group) == 1:
+        return obj
+    box = [obj]
+    td.broadcast_object_list(box, src=src, group=group)
+    return box[0]

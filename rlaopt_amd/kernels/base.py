@@ -1,0 +1,363 @@
+"""Kernel-matrix operators (mirrors rlaopt/kernels/base.py:23-520).
+
+The reference builds a symbolic pykeops ``LazyTensor`` and lets pykeops JIT a fused
+map-reduce for every product (base.py:43-47, 88-101, 183-214).  On MI355X the operator
+has two execution modes, both through ``librk_hip.so``:
+
+materialised (default when the block fits the device's HBM budget)
+    K(A1, A2) - const_scaling folded in - is written once by ``rk_kernel_materialize`` and
+    every ``A @ x`` streams it with ``rk_matmat_skinny`` (HBM-bound, the roofline kernel);
+    288 GB of HBM3E hold a 200 000 x 200 000 fp32 block (160 GB) on ONE device.
+matrix-free
+    ``rk_kernel_matmat`` recomputes the entries tile by tile (compute-bound) - used when
+    the block does not fit and for the row / block oracles whose index sets change per call
+    (base.py:104-128, kernels/utils.py:10-56).
+
+``RK_KERNEL_MODE`` = "auto" | "materialize" | "matrix_free" overrides the choice.
+"""
+
+from __future__ import annotations
+
+import os
+from typing import Any
+
+import torch
+
+from .. import dist as _dist
+from ..linops import LinOp, ScaleMixin, TwoSidedLinOp
+from ..linops.base import _BaseLinOp, _RemoteShard
+from ..linops.distributed import _DistributedLinOp, _DistributedTwoSidedLinOp
+from ..ops import get_backend
+from ..utils import _is_set, _is_torch_tensor
+from .configs import KernelConfig, _is_kernel_config
+
+_HBM_FRACTION = 0.85  # of the currently free device memory a materialised block may take
+
+
+def _mode_override() -> str:
+    mode = os.environ.get("RK_KERNEL_MODE", "auto").lower()
+    if mode not in ("auto", "materialize", "matrix_free"):
+        raise ValueError(f"RK_KERNEL_MODE={mode!r}: expected auto|materialize|matrix_free")
+    return mode
+
+
+def _fits_in_hbm(rows: int, cols: int, dtype: torch.dtype, device: torch.device) -> bool:
+    need = rows * cols * torch.empty((), dtype=dtype).element_size()
+    if device.type != "cuda":
+        return True  # host stand-in backends (tests) have no HBM budget
+    free, _total = torch.cuda.mem_get_info(device)
+    return need <= _HBM_FRACTION * free
+
+
+class _KernelBlock:
+    """K(A1[rows], A2) on one device: lazily materialised, or matrix-free."""
+
+    def __init__(self, kind: str, A1: torch.Tensor, A2: torch.Tensor, config: KernelConfig):
+        self.kind, self.A1, self.A2, self.config = kind, A1, A2, config
+        self.scale = float(getattr(config, "const_scaling", 1.0))
+        self._K = None
+        self._symmetric = A1 is A2 or (
+            A1.data_ptr() == A2.data_ptr() and A1.shape == A2.shape and A1.stride() == A2.stride()
+        )
+        mode = _mode_override()
+        if mode == "auto":
+            self.materialised = _fits_in_hbm(A1.shape[0], A2.shape[0], A1.dtype, A1.device)
+        else:
+            self.materialised = mode == "materialize"
+
+    @property
+    def K(self) -> torch.Tensor:
+        if self._K is None:
+            self._K = get_backend().kernel_materialize(
+                self.kind, self.A1, self.A2, self.config.lengthscale, scale=self.scale
+            )
+        return self._K
+
+    def matmat(self, x, diag_shift=0.0, row0=0, alpha=1.0, beta=0.0, C=None):
+        be = get_backend()
+        if self.materialised:
+            return be.matmat(self.K, x, alpha=alpha, beta=beta, C=C, diag_shift=diag_shift, row0=row0)
+        y = be.kernel_matmat(self.kind, self.A1, self.A2, self.config.lengthscale, x, scale=self.scale)
+        if diag_shift != 0.0:
+            y = y + diag_shift * x[row0 : row0 + y.shape[0]]
+        if alpha != 1.0 or beta != 0.0:
+            y = alpha * y + (beta * C if beta != 0.0 else 0.0)
+        return y
+
+    def rmatmat(self, x):
+        be = get_backend()
+        if self.materialised:
+            if self._symmetric and self.A1.shape[0] == self.A2.shape[0]:
+                return be.matmat(self.K, x)
+            return be.rmatmat(self.K, x)
+        # K(A1, A2)^T = K(A2, A1)
+        return be.kernel_matmat(self.kind, self.A2, self.A1, self.config.lengthscale, x, scale=self.scale)
+
+    def release(self):
+        self._K = None
+
+
+def _check_data(A1: Any, A2: Any, kernel_config: Any, same_device: bool):
+    _is_torch_tensor(A1, "A1")
+    _is_torch_tensor(A2, "A2")
+    if A1.ndim != 2:
+        raise ValueError(f"A1 must be a 2D tensor, got {A1.ndim}D tensor.")
+    if A2.ndim != 2:
+        raise ValueError(f"A2 must be a 2D tensor, got {A2.ndim}D tensor.")
+    if same_device and A1.device != A2.device:
+        raise ValueError("A1 and A2 must be on the same device.")
+    if A1.dtype != A2.dtype:
+        raise ValueError("A1 and A2 must have the same dtype.")
+    _is_kernel_config(kernel_config, "kernel_config")
+
+
+class _KernelLinOp(TwoSidedLinOp, ScaleMixin):
+    """Single-device kernel operator K(A1, A2) with row / block oracles."""
+
+    def __init__(self, A1, A2, kernel_config: KernelConfig, _kernel_kind: str):
+        _check_data(A1, A2, kernel_config, same_device=True)
+        self._A1, self._A2, self._kernel_config, self._kind = A1, A2, kernel_config, _kernel_kind
+        self._initialize_scaling(getattr(kernel_config, "const_scaling", 1.0))
+        self._block = _KernelBlock(_kernel_kind, A1, A2, kernel_config)
+        super().__init__(
+            device=A1.device,
+            shape=torch.Size((A1.shape[0], A2.shape[0])),
+            matvec=self._block.matmat,
+            rmatvec=self._block.rmatmat,
+            matmat=self._block.matmat,
+            rmatmat=self._block.rmatmat,
+            dtype=A1.dtype,
+        )
+
+    A1 = property(lambda self: self._A1)
+    A2 = property(lambda self: self._A2)
+    kernel_config = property(lambda self: self._kernel_config)
+
+    # fused "A @ X + shift * X" used by the solvers (saves one pass over X)
+    def _rk_shifted_matmat(self, X, shift):
+        return self._block.matmat(X, diag_shift=shift, row0=0)
+
+    def _get_kernel_linop(self, idx1=None, idx2=None) -> LinOp:
+        """Matrix-free K(A1[idx1], A2[idx2]) (base.py:104-128); scaling applied once."""
+        be, cfg = get_backend(), self._kernel_config
+        i1 = None if idx1 is None else idx1.to(self.device)
+        i2 = None if idx2 is None else idx2.to(self.device)
+        rows = self._A1.shape[0] if idx1 is None else idx1.shape[0]
+        cols = self._A2.shape[0] if idx2 is None else idx2.shape[0]
+
+        def matvec(x):
+            return be.kernel_matmat(
+                self._kind, self._A1, self._A2, cfg.lengthscale, x, scale=self._scaling,
+                idx1=i1, idx2=i2,
+            )
+
+        return LinOp(
+            device=self.device, shape=torch.Size((rows, cols)), matvec=matvec, matmat=matvec,
+            dtype=self.dtype,
+        )
+
+    def row_oracle(self, blk: torch.Tensor) -> LinOp:
+        return self._get_kernel_linop(idx1=blk)
+
+    def blk_oracle(self, blk: torch.Tensor) -> LinOp:
+        return self._get_kernel_linop(idx1=blk, idx2=blk)
+
+
+class _KernelShard(TwoSidedLinOp):
+    """Row shard K(A1[rows_i], A2) resident on one device (the role of the reference's
+    ``_CacheableKernelLinOp``, base.py:131-225, without per-call pickling or printing)."""
+
+    def __init__(self, kind, A1_rows, A2, kernel_config, device):
+        self._block = _KernelBlock(kind, A1_rows.to(device), A2.to(device), kernel_config.to(device))
+        super().__init__(
+            device=device,
+            shape=torch.Size((A1_rows.shape[0], A2.shape[0])),
+            matvec=self._block.matmat,
+            rmatvec=self._block.rmatmat,
+            matmat=self._block.matmat,
+            rmatmat=self._block.rmatmat,
+            dtype=A1_rows.dtype,
+        )
+
+    def _clear_cache(self):
+        self._block.release()
+
+
+class _UnavailableShard(_BaseLinOp):
+    """Shard of an operator built with ``use_full_kernel=False`` (base.py:383-406): only the
+    oracles are usable, the full product is not."""
+
+    def _matvec(self, x):
+        raise RuntimeError("this operator was built with use_full_kernel=False: only "
+                           "row_oracle / blk_oracle are available")
+
+    _matmat = _matvec
+
+
+def _sorted_devices(devices) -> list[torch.device]:
+    # a set has hash order (base.py:356); sort for a deterministic shard <-> device map
+    return sorted(devices, key=lambda d: (d.type, -1 if d.index is None else d.index))
+
+
+class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
+    """Row-sharded kernel operator with distributed row / block oracles."""
+
+    def __init__(self, A1, A2, kernel_config, devices, use_full_kernel, _kernel_kind, group=None):
+        self._check_inputs(A1, A2, kernel_config, devices)
+        self._kind = _kernel_kind
+        self._A1, self._A2, self._kernel_config = A1, A2, kernel_config
+        self._initialize_scaling(getattr(kernel_config, "const_scaling", 1.0))
+        devs = _sorted_devices(devices)
+        rank, size = _dist.world(group)
+        spmd = size > 1
+        parts = size if spmd else len(devs)
+        n1, n2 = A1.shape[0], A2.shape[0]
+        # base.py:297-302: torch.chunk partition of the rows of A1 (operator) and A2 (oracle)
+        self._A1_bounds = _dist.row_chunks(n1, parts)
+        self._A2_bounds = _dist.row_chunks(n2, parts)
+        self.A1_row_chunks = [torch.arange(lo, hi) for lo, hi in self._A1_bounds]
+        self.A2_row_chunks = [torch.arange(lo, hi) for lo, hi in self._A2_bounds]
+        if spmd:
+            mine = self._my_device(devs, A1)
+            self._shard_devices = [mine] * parts
+        else:
+            self._shard_devices = devs  # zip() below drops surplus devices like the reference
+        self._kernel_config_devices = {d: kernel_config.to(d) for d in set(self._shard_devices)}
+
+        def owned(i):
+            return (not spmd) or i == rank
+
+        # A2 column blocks for the row oracle stay resident on their device (base.py:305-307)
+        self.A2_chunks = [
+            A2[lo:hi].to(dev) if owned(i) else None
+            for i, ((lo, hi), dev) in enumerate(zip(self._A2_bounds, self._shard_devices))
+        ]
+        shards = []
+        for i, ((lo, hi), dev) in enumerate(zip(self._A1_bounds, self._shard_devices)):
+            shape = torch.Size((hi - lo, n2))
+            if not owned(i):
+                shards.append(_RemoteShard(dev, shape, A1.dtype))
+            elif use_full_kernel:
+                shards.append(_KernelShard(_kernel_kind, A1[lo:hi], A2, kernel_config, dev))
+            else:
+                shards.append(_UnavailableShard(dev, shape, A1.dtype))
+        super().__init__(
+            shape=torch.Size((n1, n2)), A=shards, distribution_mode="row", is_new=True,
+            group=group, spmd=spmd,
+        )
+        self.kernel_ops = shards
+        self._use_full_kernel = use_full_kernel
+
+    @staticmethod
+    def _my_device(devs, A1):
+        if len(devs) == 1:
+            return devs[0]
+        if torch.cuda.is_available():
+            cur = torch.device("cuda", torch.cuda.current_device())
+            if cur in devs:
+                return cur
+        if A1.device in devs:
+            return A1.device
+        raise ValueError("in SPMD mode `devices` must contain this rank's device")
+
+    A1 = property(lambda self: self._A1)
+    A2 = property(lambda self: self._A2)
+    kernel_config = property(lambda self: self._kernel_config)
+
+    @staticmethod
+    def _check_inputs(A1, A2, kernel_config, devices):
+        _check_data(A1, A2, kernel_config, same_device=False)
+        _is_set(devices, "devices")
+        if len(devices) == 0:
+            raise ValueError("devices must be a non-empty set.")
+        if not all(isinstance(d, torch.device) for d in devices):
+            raise ValueError("All elements in devices must be torch.device instances.")
+
+    # -- sharded fast path used by PCG / Nystrom (SPMD: state stays row-partitioned) -------
+    @property
+    def is_row_sharded(self) -> bool:
+        return self._spmd
+
+    @property
+    def row_range(self) -> tuple[int, int]:
+        """[lo, hi) of the rows of A1 owned by this rank."""
+        ids = self._local_ids()
+        return self._A1_bounds[ids[0]] if ids else (self.shape[0], self.shape[0])
+
+    @property
+    def local_device(self) -> torch.device:
+        ids = self._local_ids()
+        return self._shard_devices[ids[0] if ids else 0]
+
+    def local_matmat(self, X_full: torch.Tensor, diag_shift: float = 0.0) -> torch.Tensor:
+        """K[rows_i, :] @ X_full (+ diag_shift * X_full[rows_i]) -> local row block."""
+        ids = self._local_ids()
+        if not ids:
+            k = () if X_full.ndim == 1 else (X_full.shape[1],)
+            return torch.zeros((0, *k), dtype=X_full.dtype, device=X_full.device)
+        shard = self._A[ids[0]]
+        lo, _hi = self._A1_bounds[ids[0]]
+        if isinstance(shard, _KernelShard):
+            return shard._block.matmat(X_full.to(shard.device), diag_shift=diag_shift, row0=lo)
+        return shard @ X_full  # raises for use_full_kernel=False
+
+    def _rk_shifted_matmat(self, X, shift):
+        if self._spmd or len(self._A) != 1:
+            return None  # generic path (A @ X, then + shift * X)
+        return self.local_matmat(X, diag_shift=shift).to(X.device)
+
+    # -- oracles ---------------------------------------------------------------------------
+    def row_oracle(self, blk: torch.Tensor) -> _DistributedLinOp:
+        """K(A1[blk], A2): column-distributed - shard i multiplies K(A1[blk], A2[cols_i]) with
+        x[cols_i]; partial results are summed (base.py:408-447, utils.py:10-29)."""
+        be = get_backend()
+        ops = []
+        for i, ((lo, hi), dev) in enumerate(zip(self._A2_bounds, self._shard_devices)):
+            shape = torch.Size((blk.shape[0], hi - lo))
+            A2c = self.A2_chunks[i]
+            if A2c is None:
+                ops.append(_RemoteShard(dev, shape, self.dtype))
+                continue
+            cfg = self._kernel_config_devices[dev]
+            A1b = self._A1[blk.to(self._A1.device)].to(dev)  # gathered once per oracle
+
+            def matvec(x, A1b=A1b, A2c=A2c, cfg=cfg):
+                return be.kernel_matmat(self._kind, A1b, A2c, cfg.lengthscale, x, scale=self._scaling)
+
+            ops.append(LinOp(device=dev, shape=shape, matvec=matvec, matmat=matvec, dtype=self.dtype))
+        return _DistributedLinOp(
+            shape=torch.Size((blk.shape[0], self._A2.shape[0])), A=ops,
+            distribution_mode="column", is_new=False, group=self._group, spmd=self._spmd,
+        )
+
+    def blk_oracle(self, blk: torch.Tensor) -> _DistributedLinOp:
+        """K(A1[blk], A2[blk]): row-distributed over chunks of blk (base.py:449-505)."""
+        be = get_backend()
+        parts = len(self._shard_devices)
+        bounds = _dist.row_chunks(blk.shape[0], parts)
+        ops = []
+        for i, (lo, hi) in enumerate(bounds):
+            dev = self._shard_devices[i]
+            shape = torch.Size((hi - lo, blk.shape[0]))
+            if self._spmd and i != self._rank:
+                ops.append(_RemoteShard(dev, shape, self.dtype))
+                continue
+            cfg = self._kernel_config_devices[dev]
+            A1c = self._A1[blk[lo:hi].to(self._A1.device)].to(dev)
+            A2b = self._A2[blk.to(self._A2.device)].to(dev)
+
+            def matvec(x, A1c=A1c, A2b=A2b, cfg=cfg):
+                return be.kernel_matmat(self._kind, A1c, A2b, cfg.lengthscale, x, scale=self._scaling)
+
+            ops.append(LinOp(device=dev, shape=shape, matvec=matvec, matmat=matvec, dtype=self.dtype))
+        return _DistributedLinOp(
+            shape=torch.Size((blk.shape[0], blk.shape[0])), A=ops, distribution_mode="row",
+            is_new=False, group=self._group, spmd=self._spmd,
+        )
+
+    def shutdown(self):
+        """Release the materialised shards (base.py:507-520)."""
+        for op in self.kernel_ops:
+            if hasattr(op, "_clear_cache"):
+                op._clear_cache()
+        super().shutdown()

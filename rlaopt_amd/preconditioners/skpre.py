@@ -1,0 +1,55 @@
+"""Sketch-and-precondition (rlaopt/preconditioners/skpre.py:55-118) for tall A (m x d).
+
+Y = Omega A (s x d) is one GEMM; G = Y^T Y + rho I is an f64-accumulated Gram product; the
+d x d Cholesky runs in float64 on the host.  The reference's ordering quirk is reproduced
+on purpose: with the LOWER factor L of G the operator applied is L^T L (skpre.py:111) and
+its inverse L^-1 L^-T (skpre.py:116-117) - mutually consistent, not equal to G.  The
+inverse is applied with the explicit d x d matrix L^-1 (two small device products per
+apply instead of two triangular solves)."""
+
+from warnings import warn
+
+import torch
+
+from ..ops import get_backend
+from ..sketches import get_sketch
+from .preconditioner import Preconditioner
+
+
+class SkPre(Preconditioner):
+    def __init__(self, config):
+        super().__init__(config)
+        self.Y = None
+        self.L = None
+        self._Linv = None
+
+    def _update(self, A, device):
+        if self.config.sketch_size < A.shape[1]:
+            warn(
+                f"Sketch size ({self.config.sketch_size}) is smaller than the number of columns "
+                f"in input matrix A ({A.shape[1]}). This may lead to a poor and/or unstable "
+                "approximation."
+            )
+        be = get_backend()
+        sk = get_sketch(self.config.sketch, "left", self.config.sketch_size, A.shape[0],
+                        dtype=A.dtype, device=device)
+        Y = sk._apply_left(A)
+        G = be.gram_tn(Y, Y).cpu()
+        del Y  # the reference frees it too (skpre.py:142-153)
+        if self.config.rho != 0:
+            G.diagonal().add_(self.config.rho)
+        L = torch.linalg.cholesky(G, upper=False)
+        Linv = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=torch.float64), upper=False)
+        self.L = L.to(device=device, dtype=A.dtype)
+        self._Linv = Linv.to(device=device, dtype=A.dtype)
+
+    def _matmul(self, x):
+        be = get_backend()
+        return be.rmatmat(self.L, be.matmat(self.L, x))  # L^T (L x)
+
+    def _solve(self, x):
+        be = get_backend()
+        return be.matmat(self._Linv, be.rmatmat(self._Linv, x))  # L^-1 (L^-T x)
+
+    _inverse_matmul_1d = _solve
+    _inverse_matmul_2d = _solve

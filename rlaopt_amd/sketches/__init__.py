@@ -1,0 +1,186 @@
+"""Dense test matrices Omega (mirrors ``rlaopt.sketches``; sketch.py:16-117, gauss.py:32-52,
+ortho.py:32-56, sparse.py:32-76, factory.py:25-59).
+
+Differences from the reference, by design:
+
+* On a cuda device the Gaussian draw is ``rk_randn`` (Philox4x32-10 + Box-Muller in a HIP
+  kernel).  Its (seed, offset) are taken from torch's default CPU generator, so
+  ``torch.manual_seed`` keeps runs reproducible, and - in SPMD runs - the pair is broadcast
+  from rank 0 so every rank regenerates the SAME Omega without moving it.
+* The orthonormal sketch is CholeskyQR2 on the device (two f64-accumulated Gram products +
+  two tall GEMMs) instead of a Householder QR; the result spans the same space and differs
+  from LAPACK's Q only by column signs, to which the Nystrom approximation is invariant.
+* ``inject(...)`` feeds externally generated matrices (parity tests / benchmarks use the
+  reference's own CPU draws, SURVEY.md section 7 "RNG parity").
+"""
+
+from __future__ import annotations
+
+import contextlib
+from abc import ABC, abstractmethod
+from collections import deque
+from enum import Enum
+
+import torch
+
+from .. import dist as _dist
+from ..linops.base import _BaseLinOp
+from ..ops import get_backend
+from ..utils import _is_pos_int
+
+__all__ = ["get_sketch", "inject"]
+
+
+class _SketchSide(Enum):
+    LEFT = "left"
+    RIGHT = "right"
+
+    @classmethod
+    def _from_str(cls, value, param_name):
+        if isinstance(value, cls):
+            return value
+        if isinstance(value, str) and value.lower() in ("left", "right"):
+            return cls(value.lower())
+        raise ValueError(
+            f"Invalid value for {param_name}: {value}. Expected 'left', 'right', "
+            "_SketchSide.LEFT, or _SketchSide.RIGHT."
+        )
+
+
+class _SketchMode(Enum):
+    GAUSS = "gauss"
+    ORTHO = "ortho"
+    SPARSE = "sparse"
+
+    @classmethod
+    def _from_str(cls, value, param_name):
+        if isinstance(value, cls):
+            return value
+        if isinstance(value, str) and value.lower() in ("gauss", "ortho", "sparse"):
+            return cls(value.lower())
+        raise ValueError(
+            f"Invalid value for {param_name}: {value}. Expected 'gauss', 'ortho', 'sparse', "
+            "_SketchMode.GAUSS, _SketchMode.ORTHO, or _SketchMode.SPARSE."
+        )
+
+
+_injected: deque = deque()
+
+
+@contextlib.contextmanager
+def inject(*matrices: torch.Tensor):
+    """Within the block, successive ``get_sketch`` calls use these matrices (in order, each
+    already in its final orientation) instead of drawing new ones."""
+    _injected.extend(matrices)
+    try:
+        yield
+    finally:
+        _injected.clear()
+
+
+def _draw_seed() -> tuple[int, int]:
+    pair = torch.randint(0, 2**62, (2,), dtype=torch.int64)  # advances the default CPU generator
+    return tuple(int(v) for v in _dist.broadcast_object(pair.tolist()))
+
+
+def _device_randn(rows: int, cols: int, dtype, device) -> torch.Tensor:
+    seed, offset = _draw_seed()
+    return get_backend().randn(rows, cols, dtype, device, seed=seed, offset=offset)
+
+
+class Sketch(ABC):
+    """Omega with the four products the preconditioners use (sketch.py:75-117)."""
+
+    def __init__(self, mode, sketch_size, matrix_dim, dtype, device):
+        self.mode = _SketchSide._from_str(mode, "mode")
+        self.s, self.d, self.dtype, self.device = sketch_size, matrix_dim, dtype, device
+        _is_pos_int(sketch_size, "sketch_size")
+        want = (self.s, self.d) if self.mode is _SketchSide.LEFT else (self.d, self.s)
+        if _injected:
+            Om = _injected.popleft()
+            if tuple(Om.shape) != want:
+                raise ValueError(f"injected sketch has shape {tuple(Om.shape)}, expected {want}")
+            self.Omega_mat = Om.to(device=device, dtype=dtype)
+        else:
+            self.Omega_mat = self._generate_embedding()
+
+    @abstractmethod
+    def _generate_embedding(self) -> torch.Tensor: ...
+
+    # Omega @ x
+    def _apply_left(self, x):
+        if isinstance(x, _BaseLinOp):
+            return self.Omega_mat @ x  # -> x.__rmatmul__
+        return get_backend().matmat(self.Omega_mat, x)
+
+    # x @ Omega
+    def _apply_right(self, x):
+        if isinstance(x, _BaseLinOp):
+            return x @ self.Omega_mat
+        return get_backend().matmat(x, self.Omega_mat)
+
+    # Omega.T @ x
+    def _apply_left_trans(self, x):
+        if isinstance(x, _BaseLinOp):
+            return self.Omega_mat.T @ x
+        return get_backend().rmatmat(self.Omega_mat, x)
+
+    # x @ Omega.T
+    def _apply_right_trans(self, x):
+        if isinstance(x, _BaseLinOp):
+            return x @ self.Omega_mat.T
+        return get_backend().gemm(x, self.Omega_mat, transB=True)
+
+
+class Gauss(Sketch):
+    """randn(s, d) / sqrt(s), stored (d, s) for mode 'right' (gauss.py:46-52)."""
+
+    def _generate_embedding(self):
+        scale = self.s**-0.5
+        if self.mode is _SketchSide.RIGHT:
+            # entries are i.i.d.: draw directly in the (d, s) layout the products consume
+            return _device_randn(self.d, self.s, self.dtype, self.device) * scale
+        return _device_randn(self.s, self.d, self.dtype, self.device) * scale
+
+
+class Ortho(Sketch):
+    """Orthonormal basis of a Gaussian (d, s) matrix (ortho.py:48-56) via CholeskyQR2."""
+
+    def _generate_embedding(self):
+        be = get_backend()
+        Q = _device_randn(self.d, self.s, self.dtype, self.device)
+        for _ in range(2):
+            G = be.gram_tn(Q, Q)  # float64 (s x s)
+            R = torch.linalg.cholesky(G.cpu(), upper=True)
+            Rinv = torch.linalg.solve_triangular(
+                R, torch.eye(self.s, dtype=torch.float64), upper=True
+            )
+            Q = be.gemm(Q, Rinv.to(device=self.device, dtype=self.dtype))
+        return Q.T.contiguous() if self.mode is _SketchSide.LEFT else Q
+
+
+class Sparse(Sketch):
+    """Sparse sign embedding: zeta = min(8, s) entries of +-zeta^-1/2 per column of the
+    (s, d) matrix, colliding positions overwrite (sparse.py:52-76).  Generated with torch's
+    device RNG (O(zeta d) work, outside the hot path); applied as a dense matrix like the
+    reference does."""
+
+    def _generate_embedding(self):
+        zeta = 8 if self.s >= 8 else self.s
+        Om = torch.zeros((self.s, self.d), dtype=self.dtype, device=self.device)
+        signs = 2 * torch.bernoulli(
+            torch.full((zeta, self.d), 0.5, dtype=self.dtype, device=self.device)
+        ) - 1
+        rows = torch.randint(self.s, (zeta, self.d), device=self.device)
+        Om.scatter_(0, rows, signs)
+        Om = Om * zeta**-0.5
+        return Om.T.contiguous() if self.mode is _SketchSide.RIGHT else Om
+
+
+SKETCH_MODE_TO_CLASS = {_SketchMode.GAUSS: Gauss, _SketchMode.ORTHO: Ortho, _SketchMode.SPARSE: Sparse}
+
+
+def get_sketch(name, mode, sketch_size, matrix_dim, dtype, device) -> Sketch:
+    """Factory (factory.py:25-59): name in {'gauss','ortho','sparse'}, mode in {'left','right'}."""
+    cls = SKETCH_MODE_TO_CLASS[_SketchMode._from_str(name, "name")]
+    return cls(mode, sketch_size, matrix_dim, dtype, device)

@@ -1,0 +1,114 @@
+"""Masked block PCG (rlaopt/solvers/pcg.py:13-93), device-resident.
+
+The recurrences are the reference's true block CG (k x k alpha and beta):
+
+    AP = (A + reg I) P            alpha = (P^T AP)^-1 RZ      W += P alpha    R -= AP alpha
+    Z  = Pinv R                   RZ' = R^T Z                 beta = RZ^-1 RZ'
+    P  = Z + P beta
+
+but nothing n-long is ever touched by the host: AP is one streaming product with the
+"+ reg P" term fused in, the k x k Gram blocks come out of tall-skinny products in float64,
+the two k x k solves run in a one-workgroup kernel on the device, and the W/R and P updates
+are fused element-wise kernels reading alpha / beta from device memory - so an iteration is
+a fixed sequence of launches with no host synchronisation (the host only looks at data on
+the logging iterations, like the reference's termination test).
+
+Converged columns (system.mask False) are dropped by compacting the n x k state to the
+active columns when the mask changes (the reference re-slices every array on every step,
+pcg.py:54-90).  With a row-sharded operator the state is row-partitioned across ranks: the
+search directions are all-gathered before the product and every Gram block is all-reduced.
+"""
+
+from __future__ import annotations
+
+from typing import TYPE_CHECKING
+
+import torch
+
+from .. import dist as _dist
+from ..ops import get_backend
+from ..preconditioners import PreconditionerConfig
+from ..preconditioners import _get_precond as _pf_get_precond
+from .solver import Solver
+
+if TYPE_CHECKING:
+    from ..models import LinSys
+
+
+class PCG(Solver):
+    def __init__(self, system: "LinSys", W_init: torch.Tensor, precond_config: PreconditionerConfig,
+                 device: torch.device):
+        self.system = system
+        self.precond_config = precond_config
+        self.device = device
+        self._be = get_backend()
+        ctx = system._exec_context()
+        self._ctx = ctx
+        if W_init.ndim != 2 or W_init.shape != system.B.shape:
+            # linsys.py:39-40 unsqueezes B but not W_init; a 1-D W_init silently broadcasts in
+            # the reference - refuse it instead
+            raise ValueError(
+                f"W_init must have shape {tuple(system.B.shape)}, got {tuple(W_init.shape)}"
+            )
+        k = system.B.shape[1]
+        self._k = k
+        self._W_all = ctx.take_rows(W_init).clone().contiguous()  # n_loc x k, every column
+        self._active = list(range(k))
+        self.P = self._get_precond()
+        self._Wc = self._W_all.clone()
+        self._Rc = ctx.residual(self._Wc)  # B - (A W + reg W), local rows
+        Z = self.P._inv @ self._Rc
+        self._Pc = Z.clone()
+        self.RZ = ctx.gram(self._Rc, Z)  # k x k float64 on the device
+
+    # reference attribute names, as full arrays (debug / tests)
+    @property
+    def W(self) -> torch.Tensor:
+        self._W_all[:, self._active] = self._Wc
+        return self._ctx.gather_rows(self._W_all)
+
+    @property
+    def R(self) -> torch.Tensor:
+        return self._ctx.gather_rows(self._Rc)
+
+    @property
+    def P_(self) -> torch.Tensor:
+        return self._ctx.gather_rows(self._Pc)
+
+    def _get_precond(self):
+        P = _pf_get_precond(self.precond_config)
+        P._update(self.system.A, self.device)
+        P._update_damping(baseline_rho=self.system.reg)
+        return P
+
+    def _compact(self, mask) -> None:
+        want = [j for j in range(self._k) if bool(mask[j])]
+        want = [j for j in want if j in self._active]  # a finished column never restarts
+        if want == self._active:
+            return
+        self._W_all[:, self._active] = self._Wc
+        pos = [self._active.index(j) for j in want]
+        idx = torch.tensor(pos, device=self._Wc.device)
+        self._Wc = self._Wc[:, idx].contiguous()
+        self._Rc = self._Rc[:, idx].contiguous()
+        self._Pc = self._Pc[:, idx].contiguous()
+        self.RZ = self.RZ[idx][:, idx].contiguous()
+        self._active = want
+
+    def _step(self):
+        mask = self.system.mask
+        if not bool(mask.any()):
+            return
+        self._compact(mask)
+        if not self._active:
+            return
+        be, ctx = self._be, self._ctx
+        AP = ctx.shifted_matmat(self._Pc)            # (A + reg I) P, local rows
+        PAP = ctx.gram(self._Pc, AP)
+        alpha = be.small_solve(PAP, self.RZ)
+        be.pcg_update_wr(self._Wc, self._Rc, self._Pc, AP, alpha)
+        Z = self.P._inv @ self._Rc
+        RZ_new = ctx.gram(self._Rc, Z)
+        beta = be.small_solve(self.RZ, RZ_new)
+        be.pcg_update_p(self._Pc, Z, beta)
+        self.RZ = RZ_new

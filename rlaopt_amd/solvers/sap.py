@@ -1,0 +1,131 @@
+"""Sketch-and-project ("ASkotch") block-coordinate solver (rlaopt/solvers/sap.py:25-175).
+
+Per iteration: draw a block of coordinates, build a block preconditioner from the
+blk x blk kernel block (matrix-free, index-gathered in the kernel), estimate the step size
+1 / lambda_max(P_b^-1 (K_bb + reg I)) by power iteration, evaluate the block gradient with
+the blk x n row oracle and apply Nesterov-accelerated updates on the rows of the block.
+
+The heavy products (row oracle, block oracle, Nystrom assembly / apply) run through the HIP
+library; the n x k Nesterov bookkeeping is element-wise torch on device tensors.
+Not reproduced: the reference's ``UnboundLocalError`` for NewtonConfig with rho != reg
+(sap.py:89-111) - that case runs the power iteration like every inexact preconditioner.
+"""
+
+from __future__ import annotations
+
+from typing import TYPE_CHECKING
+
+import numpy as np
+import torch
+
+from ..linops import LinOp
+from ..preconditioners import (
+    IdentityConfig, NewtonConfig, NystromConfig, Preconditioner, PreconditionerConfig,
+)
+from ..preconditioners import _get_precond as _pf_get_precond
+from ..spectral_estimators import randomized_powering
+from .configs import SAPAccelConfig
+from .solver import Solver
+
+if TYPE_CHECKING:
+    from ..models import LinSys
+
+VALID_PRECONDS = [IdentityConfig, NewtonConfig, NystromConfig]
+
+
+class SAP(Solver):
+    def __init__(self, system: "LinSys", W_init: torch.Tensor, precond_config: PreconditionerConfig,
+                 device: torch.device, blk_sz: int, accel: bool,
+                 accel_config: SAPAccelConfig | None, power_iters: int):
+        self.system = system
+        if type(precond_config) not in VALID_PRECONDS:
+            raise TypeError(
+                f"Valid preconditioner configs for SAP are {VALID_PRECONDS}, "
+                f"but received {type(precond_config)}"
+            )
+        self.precond_config = precond_config
+        self._W = W_init.clone()
+        self.device = device
+        self.blk_sz, self.accel, self.accel_config = blk_sz, accel, accel_config
+        self.power_iters = power_iters
+        n = system.A.shape[0]
+        self.probs = torch.ones(n) / n
+        self._blocks = None   # optional injected block sequence (parity runs)
+        self._starts = None   # optional injected power-iteration start vectors
+        if accel:
+            mu, nu = accel_config.mu, accel_config.nu
+            self.beta = 1 - (mu / nu) ** 0.5
+            self.gamma = 1 / (mu * nu) ** 0.5
+            self.alpha = 1 / (1 + self.gamma * nu)
+            self.V = self._W.clone()
+            self.Y = self._W.clone()
+
+    @property
+    def W(self):
+        return self._W
+
+    def inject_draws(self, blocks=None, starts=None):
+        """Feed externally drawn blocks / power-iteration start vectors (iterables)."""
+        self._blocks = iter(blocks) if blocks is not None else None
+        self._starts = iter(starts) if starts is not None else None
+
+    def _get_precond(self, blk: torch.Tensor) -> Preconditioner:
+        P = _pf_get_precond(self.precond_config)
+        P._update(self.system.A_blk_oracle(blk), self.device)
+        P._update_damping(baseline_rho=self.system.reg)
+        return P
+
+    def _get_blk(self) -> torch.Tensor:
+        if self._blocks is not None:
+            return next(self._blocks)
+        try:
+            return torch.multinomial(self.probs, self.blk_sz, replacement=False)
+        except RuntimeError as e:  # torch.multinomial is limited to 2**24 categories
+            if "number of categories cannot exceed" not in str(e):
+                raise
+            picks = np.random.choice(self.probs.shape[0], size=self.blk_sz, replace=False)
+            return torch.from_numpy(picks)
+
+    def _get_stepsize(self, blk: torch.Tensor, blk_precond: Preconditioner) -> float:
+        if isinstance(self.precond_config, NewtonConfig) and self.precond_config.rho == self.system.reg:
+            return 1.0  # exact block solve
+        K_bb = self.system.A_blk_oracle(blk)
+        reg = self.system.reg
+        S = LinOp(
+            device=self.device,
+            shape=torch.Size((self.blk_sz, self.blk_sz)),
+            matvec=blk_precond._inverse_matmul_compose(lambda v: K_bb @ v + reg * v),
+            dtype=self._W.dtype,
+        )
+        v0 = next(self._starts).to(device=self.device, dtype=self._W.dtype) if self._starts else None
+        max_eig, _ = randomized_powering(S, max_iters=self.power_iters, v0=v0)
+        return float(max_eig) ** -1.0
+
+    def _get_block_update(self, W, B, blk, blk_precond):
+        grad = self.system.A_row_oracle(blk) @ W + self.system.reg * W[blk, :] - B[blk, :]
+        return blk_precond._inv @ grad
+
+    def _step(self):
+        mask = self.system.mask
+        if not bool(mask.any()):
+            return
+        cols = torch.nonzero(mask)[:, 0].to(self._W.device)
+        blk = self._get_blk()
+        blk_precond = self._get_precond(blk)
+        eta = self._get_stepsize(blk, blk_precond)
+        blk_d = blk.to(self._W.device)
+        base = self.Y if self.accel else self._W
+        loc = base[:, cols]
+        d = self._get_block_update(loc, self.system.B[:, cols], blk_d, blk_precond)
+        if not self.accel:
+            Wm = self._W[:, cols]
+            Wm[blk_d] -= eta * d
+            self._W[:, cols] = Wm
+            return
+        Wm = loc.clone()                      # W <- Y, then the block step
+        Wm[blk_d] -= eta * d
+        Vm = self.beta * self.V[:, cols] + (1 - self.beta) * loc
+        Vm[blk_d] -= (eta * self.gamma) * d
+        self._W[:, cols] = Wm
+        self.V[:, cols] = Vm
+        self.Y[:, cols] = self.alpha * Vm + (1 - self.alpha) * Wm

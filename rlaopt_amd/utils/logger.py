@@ -1,0 +1,44 @@
+"""Iteration logger (rlaopt/utils/logger.py:10-51): every ``log_freq`` iterations it calls
+``log_fn`` and records ``iter_time`` (wall time since the previous log, excluding the time
+spent inside the log callback) and ``cum_time``.  wandb is optional: it is imported only
+when ``wandb_kwargs`` is given (the GPU boxes have no network)."""
+
+import time
+from typing import Callable
+
+__all__ = ["Logger"]
+
+
+class Logger:
+    def __init__(self, log_freq: int, log_fn: Callable, wandb_kwargs: dict | None):
+        self.log_freq = log_freq
+        self.log_fn = log_fn
+        self._wandb = None
+        if wandb_kwargs is not None:
+            import wandb  # noqa: PLC0415 - optional dependency
+
+            self._wandb = wandb
+            wandb.init(**wandb_kwargs)
+        self.log_in_wandb = self._wandb is not None
+        self.iter_time = 0.0
+        self.cum_time = 0.0
+        self._tick = time.time()
+
+    def _compute_log(self, i: int, *args, **kwargs):
+        if i % self.log_freq:
+            return None
+        self.iter_time = time.time() - self._tick
+        self.cum_time += self.iter_time
+        entry = {
+            "iter_time": self.iter_time,
+            "cum_time": self.cum_time,
+            "metrics": self.log_fn(*args, **kwargs),
+        }
+        if self._wandb is not None:
+            self._wandb.log(entry, step=i)
+        self._tick = time.time()  # the callback's own time is not charged to the solver
+        return entry
+
+    def _terminate(self):
+        if self._wandb is not None:
+            self._wandb.finish()

@@ -1,0 +1,67 @@
+"""CPU stand-in for ``rlaopt_amd.ops.HipBackend`` built on the oracle (TEST ONLY).
+
+It lets the CPU suite drive the package's HOST logic - operator sharding, collectives,
+Nystrom small-matrix algebra, PCG/SAP control flow, LinSys cadence - without a GPU.  It is
+installed explicitly with ``rlaopt_amd.ops.use_backend(OracleBackend())``; the package never
+falls back to it.
+"""
+
+import torch
+
+from oracle import kernels as ok
+
+
+def _two_d(v):
+    return (v[:, None], True) if v.ndim == 1 else (v, False)
+
+
+class OracleBackend:
+    name = "oracle-cpu"
+
+    def kernel_materialize(self, kind, X1, X2, lengthscale, scale=1.0, idx1=None, idx2=None, out=None):
+        A1 = X1 if idx1 is None else X1[idx1]
+        A2 = X2 if idx2 is None else X2[idx2]
+        return ok.kernel_matrix(kind, A1, A2, lengthscale, scale)
+
+    def kernel_matmat(self, kind, X1, X2, lengthscale, V, scale=1.0, idx1=None, idx2=None):
+        return ok.kernel_matmat(kind, X1, X2, lengthscale, V, scale, idx1=idx1, idx2=idx2)
+
+    def matmat(self, A, V, alpha=1.0, beta=0.0, C=None, diag_shift=0.0, row0=0):
+        V2, sq = _two_d(V)
+        Y = alpha * (A @ V2)
+        if beta != 0.0:
+            Y = Y + beta * (C[:, None] if C.ndim == 1 else C)
+        if diag_shift != 0.0:
+            Y = Y + diag_shift * V2[row0 : row0 + A.shape[0]]
+        return Y[:, 0] if sq else Y
+
+    def rmatmat(self, A, V, alpha=1.0, beta=0.0, C=None, out_f64=False):
+        V2, sq = _two_d(V)
+        if out_f64:
+            Y = alpha * (A.double().T @ V2.double())
+        else:
+            Y = alpha * (A.T @ V2)
+        if beta != 0.0:
+            Y = Y + beta * (C[:, None] if C.ndim == 1 else C)
+        return Y[:, 0] if sq else Y
+
+    def gemm(self, A, B, transA=False, transB=False, alpha=1.0):
+        return alpha * ((A.T if transA else A) @ (B.T if transB else B))
+
+    def gram_tn(self, A, B):
+        return A.double().T @ B.double()
+
+    def pcg_update_wr(self, W, R, P, AP, alpha):
+        a = alpha.to(W.dtype)
+        W += P @ a
+        R -= AP @ a
+
+    def pcg_update_p(self, P, Z, beta):
+        P.copy_(Z + P @ beta.to(P.dtype))
+
+    def small_solve(self, A, B):
+        return torch.linalg.solve(A, B)
+
+    def randn(self, rows, cols, dtype, device, seed, offset=0, scale=1.0):
+        g = torch.Generator().manual_seed((int(seed) * 1000003 + int(offset)) % (2**63))
+        return scale * torch.randn(rows, cols, dtype=dtype, generator=g).to(device)
