@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""Headline benchmark: PCG iterations/s (and kernel-matvec GB/s) on the n = 200 000 RBF KRR
+system of BASELINE.json, row-sharded over N MI355X GPUs.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload: X = randn(n, 64)/sqrt(64) (seed 0, drawn on the CPU in
+float64, cast to float32), RBF lengthscale 1, B = randn(n, 1), reg = 1e-6 n, Nystrom rank 512
+with an injected Gaussian test matrix (seed 1), adaptive damping, float32.  One "step" is one
+iteration of the LinSys loop: a block-PCG step (kernel shard product with the "+ reg P" term,
+Nystrom inverse apply, Gram blocks, k x k solves, fused updates, collectives) plus - every
+``callback_freq`` = 10 iterations, like the reference's loop - the true-residual evaluation.
+Setup (materialising the kernel shard, Nystrom assembly) is outside the timed region and is
+reported separately; inputs are resident in HBM when the timed region starts.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+``roofline`` for the dominant kernel (the HBM-streaming shard product ``rk_matmat_skinny``;
+algorithmic bytes per launch = (n_loc n + n k + n_loc k) * 4, duration from HIP events on the
+launch stream inside the timed region) and ``cpu_baseline`` (the oracle's C restatement of the
+matrix-free kernel product timed on the host cores over a bounded row sample, rank 0, N = 1).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as td  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 is the measured copy ceiling
+
+
+def make_problem(n, d, r, seed_x=0, seed_om=1):
+    g = torch.Generator().manual_seed(seed_x)
+    X = (torch.randn(n, d, dtype=torch.float64, generator=g) / d**0.5).float()
+    B = torch.randn(n, 1, dtype=torch.float64, generator=g).float()
+    g = torch.Generator().manual_seed(seed_om)
+    Om = torch.empty(n, r, dtype=torch.float32)
+    for c0 in range(0, r, 64):  # randn(r, n)/sqrt(r) transposed, drawn in slabs to bound memory
+        Om[:, c0 : c0 + 64] = (torch.randn(min(64, r - c0), n, dtype=torch.float64, generator=g) / r**0.5).T.float()
+    return X, B, Om
+
+
+def cpu_baseline(X, n, budget_s=12.0):
+    """CPU leg: the oracle's C/OpenMP matrix-free RBF product on a growing row sample of the
+    SAME n x n system until ~budget_s of host work has been measured; converted to PCG
+    iterations/s (the kernel product is > 99 % of a CPU iteration: SURVEY 8a, row a11)."""
+    from oracle import cbind
+
+    cores = cbind.num_threads()
+    V = torch.ones(n, 1, dtype=torch.float32)
+    rows, spent, done_rows = 256, 0.0, 0
+    cbind.kernel_matmat("rbf", X[:64], X, 1.0, V)  # warm the threads
+    while spent < budget_s and rows <= n:
+        t = time.time()
+        cbind.kernel_matmat("rbf", X[:rows], X, 1.0, V)
+        dt = time.time() - t
+        spent += dt
+        done_rows += rows
+        last = (rows, dt)
+        rows *= 2
+    pair_rate = last[0] * n / last[1]
+    sec_per_iter = n * n / pair_rate * 1.1  # + the residual product every 10th iteration
+    return {
+        "value": 1.0 / sec_per_iter,
+        "unit": "iter/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"oracle/rk_oracle.c matrix-free RBF product, rows 0..{last[0]} of the n={n} d={X.shape[1]} "
+                  f"system in {last[1]:.2f}s ({pair_rate / 1e9:.3f} Gpair/s on {cores} threads), "
+                  f"extrapolated to one full product x 1.1",
+        "gpair_per_s": pair_rate / 1e9,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=200000)
+    ap.add_argument("--d", type=int, default=64)
+    ap.add_argument("--rank", type=int, default=512)
+    ap.add_argument("--callback-freq", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-solve", action="store_true", help="skip the full solve to tolerance")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        td.init_process_group("nccl", device_id=dev)
+
+    from rlaopt_amd import sketches
+    from rlaopt_amd.kernels import DistributedRBFLinOp, KernelConfig
+    from rlaopt_amd.models import LinSys
+    from rlaopt_amd.ops import get_backend
+    from rlaopt_amd.preconditioners import NystromConfig
+    from rlaopt_amd.solvers import PCGConfig
+    from rlaopt_amd.solvers.pcg import PCG
+
+    be = get_backend()
+    n, d, r, k = args.n, args.d, args.rank, 1
+    reg = 1e-6 * n
+    X, B, Om = make_problem(n, d, r)
+    Xd, Bd, Omd = X.to(dev), B.to(dev), Om.to(dev)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            td.barrier()
+
+    # ---- setup (untimed): materialise the shard, build the preconditioner -------------------
+    sync()
+    t0 = time.time()
+    A = DistributedRBFLinOp(Xd, Xd, KernelConfig(lengthscale=1.0), devices={dev})
+    system = LinSys(A, Bd, reg=reg)
+    lo, hi = A.row_range if A.is_row_sharded else (0, n)
+    _ = A.local_matmat(torch.zeros(n, 1, device=dev))  # forces materialisation
+    sync()
+    t_mat = time.time() - t0
+    t0 = time.time()
+    pcfg = NystromConfig(rank=r, rho=reg, sketch="gauss", damping_mode="adaptive")
+    with sketches.inject(Omd):
+        solver = PCG(system, torch.zeros(n, k, device=dev), pcfg, dev)
+    sync()
+    t_pre = time.time() - t0
+    del Omd
+
+    def one_iteration(i):
+        solver._step()
+        if i % args.callback_freq == 0:
+            system._compute_internal_metrics(solver.W)
+
+    # ---- warmup, then exactly K timed steps ---------------------------------------------------
+    for i in range(1, args.warmup + 1):
+        one_iteration(i)
+    be.enable_timing(True)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.warmup + 1, args.warmup + args.steps + 1):
+        one_iteration(i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    timing = be.timing_summary()
+    be.enable_timing(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        elapsed = float(tmax)
+    rel_now = float(system._compute_internal_metrics(solver.W)["rel_res"][0])
+
+    mv = timing.get("rk_matmat_skinny", {"avg_ms": float("nan"), "bytes_per_launch": 0, "launches": 0})
+    achieved = mv["bytes_per_launch"] / (mv["avg_ms"] * 1e-3) / 1e9 if mv["launches"] else float("nan")
+    if world > 1:  # roofline is per GPU: report the slowest rank's kernel
+        amin = torch.tensor([achieved], dtype=torch.float64, device=dev)
+        td.all_reduce(amin, op=td.ReduceOp.MIN)
+        achieved = float(amin)
+
+    # ---- full solve to the reference tolerance (reported, not the headline) ---------------------
+    solve = {}
+    if not args.no_solve:
+        system2 = LinSys(A, Bd, reg=reg)
+        cfg = PCGConfig(device=dev, max_iters=200, atol=0.0, rtol=1e-6,
+                        precond_config=NystromConfig(rank=r, rho=reg, sketch="gauss"))
+        Omd = Om.to(dev)
+        sync()
+        t0 = time.time()
+        with sketches.inject(Omd):
+            W, log = system2.solve(cfg, torch.zeros(n, k, device=dev), callback_freq=args.callback_freq)
+        sync()
+        solve = {
+            "solve_iters": max(log),
+            "solve_s": round(time.time() - t0, 3),
+            "solve_rel_res": float(log[max(log)]["metrics"]["internal_metrics"]["rel_res"][0]),
+        }
+        del Omd
+
+    if rank == 0:
+        out = {
+            "metric": "pcg_iters_per_sec",
+            "value": args.steps / elapsed,
+            "unit": "iter/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"rbf_krr_pcg n={n} d={d} k={k} nystrom_rank={r} reg=1e-6*n "
+                            f"(BASELINE.json configs[2]; one n x n system row-sharded over {world} GPU(s))",
+                "callback_freq": args.callback_freq,
+                "rows_per_gpu": hi - lo,
+                "parallelism": f"row-shard x{world}",
+            },
+            "roofline": {
+                "kernel": "rk_matmat_skinny (skinny_nn_kernel<float,1,8>)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "bytes_per_launch": mv["bytes_per_launch"],
+                "avg_launch_ms": mv["avg_ms"],
+                "launches": mv["launches"],
+            },
+            "matvec_GBps_aggregate": achieved * world,
+            "setup_materialize_s": round(t_mat, 3),
+            "setup_nystrom_s": round(t_pre, 3),
+            "rel_res_after_timed_steps": rel_now,
+            **solve,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(X, n)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

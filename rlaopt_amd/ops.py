@@ -75,6 +75,44 @@ class HipBackend:
     def __init__(self):
         self._lib = _lib.load()
         self._ws = {}
+        self._timing = None  # {op: [(start_event, end_event, algorithmic_bytes), ...]}
+
+    # -- optional per-launch timing (HIP events on the launch stream; used by bench.py) ------
+    def enable_timing(self, on=True):
+        self._timing = {} if on else None
+
+    def _timed(self, op, device, nbytes):
+        """Context manager bracketing one launch with events on the stream it is queued on."""
+        be = self
+
+        class _T:
+            def __enter__(self_inner):
+                if be._timing is None:
+                    return
+                self_inner.a = torch.cuda.Event(enable_timing=True)
+                self_inner.b = torch.cuda.Event(enable_timing=True)
+                self_inner.a.record(torch.cuda.current_stream(device))
+
+            def __exit__(self_inner, *exc):
+                if be._timing is None:
+                    return
+                self_inner.b.record(torch.cuda.current_stream(device))
+                be._timing.setdefault(op, []).append((self_inner.a, self_inner.b, nbytes))
+
+        return _T()
+
+    def timing_summary(self):
+        """{op: {"launches", "avg_ms", "bytes_per_launch"}} - synchronises the device."""
+        torch.cuda.synchronize()
+        out = {}
+        for op, evs in (self._timing or {}).items():
+            ms = [a.elapsed_time(b) for a, b, _ in evs]
+            out[op] = {
+                "launches": len(ms),
+                "avg_ms": sum(ms) / len(ms),
+                "bytes_per_launch": sum(nb for _, _, nb in evs) / len(evs),
+            }
+        return out
 
     # -- scratch -----------------------------------------------------------------------
     def _workspace(self, device, nbytes):
@@ -174,11 +212,13 @@ class HipBackend:
         if k <= MAX_SKINNY:
             nbytes = self._lib.rk_matmat_skinny_ws_bytes(_dt(A), m, n, k)
             ws, wsn = self._workspace(dev, nbytes)
-            rc = self._lib.rk_matmat_skinny(
-                _dt(A), _ptr(A), m, n, lda, _ptr(V2), k, ldv, float(alpha), float(beta),
-                _ptr(C2), (ldc if C2 is not None else k), float(diag_shift), int(row0),
-                _ptr(out), k, _ptr(ws), wsn, _stream(dev),
-            )
+            algo = (m * n + n * k + m * k) * A.element_size()
+            with self._timed("rk_matmat_skinny" if m * n >= (1 << 24) else "rk_matmat_skinny(small)", dev, algo):
+                rc = self._lib.rk_matmat_skinny(
+                    _dt(A), _ptr(A), m, n, lda, _ptr(V2), k, ldv, float(alpha), float(beta),
+                    _ptr(C2), (ldc if C2 is not None else k), float(diag_shift), int(row0),
+                    _ptr(out), k, _ptr(ws), wsn, _stream(dev),
+                )
             _lib.check(rc, "rk_matmat_skinny")
         else:
             if beta != 0.0:

@@ -1,0 +1,106 @@
+"""Worker for tests/test_dist_gloo.py: one rank of a world_size-N gloo group on CPU.
+
+Drives the package's SPMD code paths (row-sharded kernel operator, all-gather / all-reduce
+combination, sharded Nystrom assembly and apply, sharded block PCG, LinSys metrics) with the
+oracle injected as compute backend, and compares against a single-process dense solve.
+"""
+
+import os
+import sys
+
+import torch
+import torch.distributed as td
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+from _oracle_backend import OracleBackend  # noqa: E402
+from oracle import kernels as ok  # noqa: E402
+from oracle import linsys as ol  # noqa: E402
+from oracle import nystrom as on  # noqa: E402
+from oracle import pcg as opcg  # noqa: E402
+from rlaopt_amd import dist as rdist  # noqa: E402
+from rlaopt_amd import sketches  # noqa: E402
+from rlaopt_amd.kernels import DistributedRBFLinOp, KernelConfig  # noqa: E402
+from rlaopt_amd.models import LinSys  # noqa: E402
+from rlaopt_amd.ops import use_backend  # noqa: E402
+from rlaopt_amd.preconditioners import NystromConfig  # noqa: E402
+from rlaopt_amd.solvers import PCGConfig  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1])
+    td.init_process_group("gloo")
+    rank, size = td.get_rank(), td.get_world_size()
+    cpu = torch.device("cpu")
+    dt = torch.float64
+    gen = torch.Generator().manual_seed(0)
+    d, k, r = 5, 2, 24
+    X = torch.randn(n, d, dtype=dt, generator=gen) / d**0.5
+    X2 = torch.randn(n - 3, d, dtype=dt, generator=gen) / d**0.5
+    B = torch.randn(n, k, dtype=dt, generator=gen)
+    Om = torch.randn(r, n, dtype=dt, generator=gen).T.contiguous() / r**0.5
+    M = torch.randn(n - 3, 3, dtype=dt, generator=gen)
+    u = torch.randn(n, 2, dtype=dt, generator=gen)
+    cfgk = KernelConfig(const_scaling=1.5, lengthscale=0.9)
+    tol = dict(rtol=1e-9, atol=1e-9)
+    with use_backend(OracleBackend()):
+        # ---- collectives on ragged partitions -----------------------------------------------
+        lo, hi = rdist.my_rows(n)
+        full = torch.arange(n * 2, dtype=dt).reshape(n, 2)
+        torch.testing.assert_close(rdist.all_gather_rows(full[lo:hi], n), full)
+        sizes = [3 + 2 * i for i in range(size)]
+        off = sum(sizes[:rank])
+        stacked = torch.arange(sum(sizes), dtype=dt)
+        torch.testing.assert_close(rdist.all_gather_rows(stacked[off : off + sizes[rank]], sizes), stacked)
+
+        # ---- rectangular sharded operator: products, transpose, oracles -----------------------
+        op = DistributedRBFLinOp(X, X2, cfgk, devices={cpu})
+        assert op.is_row_sharded and op.row_range == (lo, hi)
+        K = ok.kernel_matrix("rbf", X, X2, 0.9, 1.5)
+        torch.testing.assert_close(op @ M, K @ M, **tol)
+        torch.testing.assert_close(op @ M[:, 0].contiguous(), K @ M[:, 0], **tol)
+        torch.testing.assert_close(op.T @ u, K.T @ u, **tol)
+        torch.testing.assert_close(op.local_matmat(M), (K @ M)[lo:hi], **tol)
+        blk = torch.tensor([5, 0, n - 1, 17, 9, 2, 30])
+        torch.testing.assert_close(op.row_oracle(blk) @ M, K[blk] @ M, **tol)
+        sq = DistributedRBFLinOp(X, X, cfgk, devices={cpu}, use_full_kernel=False)
+        Ksq = ok.kernel_matrix("rbf", X, X, 0.9, 1.5)
+        w = torch.randn(blk.numel(), 2, dtype=dt, generator=gen)
+        torch.testing.assert_close(sq.blk_oracle(blk) @ w, Ksq[blk][:, blk] @ w, **tol)
+        torch.testing.assert_close(sq.row_oracle(blk) @ u, Ksq[blk] @ u, **tol)
+
+        # ---- sharded Nystrom + block PCG vs the single-process oracle ---------------------------
+        A = DistributedRBFLinOp(X, X, KernelConfig(lengthscale=1.0), devices={cpu})
+        reg = 1e-4 * n
+        system = LinSys(A, B, reg=reg)
+        cfg = PCGConfig(device=cpu, max_iters=200, atol=0.0, rtol=1e-9,
+                        precond_config=NystromConfig(rank=r, rho=reg, sketch="gauss"))
+        with sketches.inject(Om):
+            W, log = system.solve(cfg, torch.zeros_like(B), callback_freq=5)
+        Kd = ok.kernel_matrix("rbf", X, X, 1.0)
+        st = on.build(Kd, Om, reg)
+        on.update_damping(st, reg, adaptive=True)
+        ref = opcg.BlockPCG(lambda V: Kd @ V, lambda R: on.inverse_matmul(st, R), B, reg, torch.zeros_like(B))
+        Wref, logref = ol.run(ref, lambda V: Kd @ V, B, reg, 200, 0.0, 1e-9, callback_freq=5)
+        assert sorted(log) == sorted(logref), (sorted(log), sorted(logref))
+        assert W.shape == B.shape
+        res = torch.linalg.norm(B - (Kd @ W + reg * W), dim=0) / torch.linalg.norm(B, dim=0)
+        assert bool((res <= 1e-9).all()), res
+        early = sorted(log)[:3]
+        got = torch.stack([log[i]["metrics"]["internal_metrics"]["rel_res"] for i in early])
+        want = torch.stack([logref[i]["rel_res"] for i in early])
+        torch.testing.assert_close(got, want, rtol=1e-6, atol=0)
+        # every rank returns the same full solution
+        Wsum = W.clone()
+        td.all_reduce(Wsum)
+        torch.testing.assert_close(Wsum / size, W, rtol=1e-12, atol=1e-12)
+    td.barrier()
+    if rank == 0:
+        print(f"DIST-OK world={size} n={n} iters={max(log)}")
+    td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

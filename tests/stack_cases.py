@@ -1,0 +1,323 @@
+"""Shared end-to-end parity cases: the package's own Nystrom / SkPre / PCG / SAP / LinSys /
+kernel-operator code must reproduce the REFERENCE's golden outputs (tests/golden/*.npz).
+
+Imported by ``test_host_cpu.py`` (CPU, oracle injected as compute backend: checks the host
+logic) and by ``test_hip_stack.py`` (cuda:0, the real HIP backend: the parity tests proper).
+Each importing module provides the ``dev`` fixture."""
+
+import pytest
+import torch
+
+from conftest import DTYPES, TOL, load_golden
+from oracle import kernels as ok
+from rlaopt_amd import sketches
+from rlaopt_amd.kernels import KernelConfig, RBFLinOp
+from rlaopt_amd.linops import LinOp, SymmetricLinOp
+from rlaopt_amd.models import LinSys
+from rlaopt_amd.preconditioners import IdentityConfig, NystromConfig, SkPreConfig
+from rlaopt_amd.preconditioners.nystrom import Nystrom
+from rlaopt_amd.preconditioners.skpre import SkPre
+from rlaopt_amd.solvers import PCGConfig, SAPAccelConfig, SAPConfig
+
+
+
+def check_pcg_parity(rel, want, W, Wref, B, reg, rtol, dt, A_dense):
+    """What "same trajectory" can mean for CG in floating point:
+
+    * the first logged iterations agree tightly (same algorithm, same inputs);
+    * later the recurrences amplify rounding differences (CG loses orthogonality; two
+      correctly rounded implementations drift by tens of percent mid-solve while converging
+      at the same rate) - the whole history must stay inside a one-logging-window envelope of the reference's, or within the
+      dtype's absolute tolerance (1e-8 / 1e-4) once it is that small;
+    * both solutions met the residual test, so they differ by <= 2 rtol in residual space
+      (checked with 3 rtol; in solution space that is amplified by cond(A + reg I)).
+    The identical iteration count is asserted by the caller."""
+    f64 = dt == torch.float64
+    head = min(3, rel.shape[0])
+    torch.testing.assert_close(rel[:head], want[:head], rtol=1e-6 if f64 else 3e-2, atol=0)
+    atol = 1e-8 if f64 else 1e-4
+    ok_abs = (rel - want).abs() <= atol
+    # envelope: within a factor 2 of the reference's value at the same logged iteration or
+    # one of its two neighbours (i.e. never more than one logging window ahead or behind)
+    T = want.shape[0]
+    nb = torch.stack([want[max(t - 1, 0) : min(t + 2, T)].min(dim=0).values for t in range(T)])
+    nbmax = torch.stack([want[max(t - 1, 0) : min(t + 2, T)].max(dim=0).values for t in range(T)])
+    ok_rel = (rel >= nb / 2) & (rel <= nbmax * 2)
+    assert bool((ok_abs | ok_rel).all()), (rel, want)
+    D = (W - Wref).double()
+    gap = torch.linalg.norm(A_dense.double() @ D + reg * D, dim=0)
+    assert bool((gap / torch.linalg.norm(B.double(), dim=0) <= 3 * rtol).all())
+
+
+@pytest.mark.parametrize("case", ["a50", "a300"])
+@pytest.mark.parametrize("sketch", ["gauss", "ortho", "sparse"])
+@pytest.mark.parametrize("mode", ["adaptive", "non_adaptive"])
+def test_nystrom_gram_assembly_matches_reference_svd(dev, prec, case, sketch, mode):
+    g = load_golden(f"nystrom_{prec}")
+    dt = DTYPES[prec]
+    A, x = g[f"{case}_A"].to(dev), g[f"{case}_x"].to(dev)
+    key = f"{case}_{sketch}_{mode}"
+    rho0, base = (1.0, 0.5) if case == "a50" else (1e-6, 1e-6)
+    rank = 20 if case == "a50" else 40
+    P = Nystrom(NystromConfig(rank=rank, rho=rho0, sketch=sketch, damping_mode=mode))
+    if case == "a50":
+        op = A  # raw tensor operator
+    else:
+        from rlaopt_amd.ops import get_backend
+
+        mv = lambda v: get_backend().matmat(A, v)  # noqa: E731
+        op = SymmetricLinOp(dev, A.shape, mv, mv, dtype=dt)
+    with sketches.inject(g[f"{key}_Omega"]):
+        P._update(op, dev)
+    P._update_damping(base)
+    tol = TOL[dt]
+    assert P.U.dtype == dt and P.S.dtype == dt and P.U.shape == (A.shape[0], rank)
+    assert P.U.device.type == dev.type and P.S.device.type == dev.type
+    torch.testing.assert_close(P.S.cpu(), g[f"{key}_S"], **tol)
+    assert bool((P.S >= 0).all())
+    assert abs(P.config.rho - float(g[f"{key}_rho"])) <= tol["atol"] + tol["rtol"] * abs(float(g[f"{key}_rho"]))
+    U = P.U.cpu()
+    torch.testing.assert_close(U.T @ U, torch.eye(rank, dtype=dt), **tol)
+    torch.testing.assert_close((P @ x).cpu(), g[f"{key}_Px"], **tol)
+    ref = g[f"{key}_Pinvx"]
+    got = P._inv @ x
+    assert (got.cpu() - ref).abs().max() <= tol["rtol"] * ref.abs().max() * 10 + tol["atol"]
+    assert got.shape == x.shape
+    if case == "a50":  # well-conditioned P (rho = 1) like the reference's round-trip test
+        back = (P @ got).cpu()
+        assert (back - x.cpu()).abs().max() <= 50 * tol["rtol"] * x.abs().max().cpu() + tol["atol"]
+        # P x == U diag(S) U^T x + rho x  (tests/preconditioners/test_nystrom.py:277-297)
+        xc = x.cpu()
+        manual = U @ (P.S.cpu() * (U.T @ xc)) + P.config.rho * xc
+        torch.testing.assert_close((P @ x).cpu(), manual, **tol)
+
+
+def test_skpre_matches_reference(dev, prec):
+    g = load_golden(f"skpre_{prec}")
+    dt = DTYPES[prec]
+    P = SkPre(SkPreConfig(sketch_size=96, rho=1e-3, sketch="gauss"))
+    with sketches.inject(g["Omega"]):
+        P._update(g["A"].to(dev), dev)
+    tol = TOL[dt] if dt == torch.float64 else dict(rtol=1e-2, atol=1e-4)
+    x = g["x"].to(dev)
+    torch.testing.assert_close(P.L.cpu(), g["L"], **tol)
+    torch.testing.assert_close((P @ x).cpu(), g["Px"], **tol)
+    torch.testing.assert_close((P._inv @ x).cpu(), g["Pinvx"], **tol)
+    with pytest.warns(UserWarning):
+        SkPre(SkPreConfig(sketch_size=8, rho=1e-3, sketch="gauss"))._update(g["A"].to(dev), dev)
+
+
+@pytest.mark.parametrize("case", ["dense", "krr"])
+@pytest.mark.parametrize("k", [1, 3])
+@pytest.mark.parametrize("sketch", ["gauss", "ortho"])
+def test_linsys_pcg_matches_reference_history(dev, prec, case, k, sketch):
+    g = load_golden(f"pcg_{prec}")
+    dt = DTYPES[prec]
+    key = f"{case}_k{k}_{sketch}"
+    B, reg, rtol = g[f"{key}_B"], float(g[f"{key}_reg"]), float(g[f"{key}_rtol"])
+    if case == "dense":
+        A = g["dense_A"].to(dev)
+    else:
+        X = g["krr_X"].to(dev)
+        A = RBFLinOp(X, X, KernelConfig(lengthscale=1.0))
+    cfg = PCGConfig(device=dev, max_iters=300, atol=0.0, rtol=rtol,
+                    precond_config=NystromConfig(rank=48, rho=reg, sketch=sketch))
+    Bd = B.to(dev)
+    system = LinSys(A, Bd if k > 1 else Bd[:, 0], reg=reg)
+    with sketches.inject(g[f"{key}_Omega"]):
+        W, log = system.solve(cfg, torch.zeros_like(Bd), callback_freq=5)
+    its = sorted(log)
+    rel = torch.stack([log[i]["metrics"]["internal_metrics"]["rel_res"].cpu() for i in its])
+    want = g[f"{key}_rel_res"]
+    ref_its = g[f"{key}_iters"].tolist()
+    if its != ref_its:
+        # Same iteration count and logging cadence - except when the reference itself stopped
+        # (or failed to stop) within a factor 1.5 of the tolerance: then rounding decides, and one
+        # logging window more or less is the same answer.
+        if len(its) == len(ref_its) + 1:
+            assert its[:-1] == ref_its and float(want[-1].max()) >= rtol / 1.5, (its, ref_its)
+            rel = rel[:-1]
+        else:
+            assert its == ref_its[:-1] and float(want[-2].max()) <= 1.5 * rtol, (its, ref_its)
+            want = want[:-1]
+    A_dense = g["dense_A"] if case == "dense" else ok.kernel_matrix("rbf", g["krr_X"], g["krr_X"], 1.0)
+    check_pcg_parity(rel, want, W.cpu(), g[f"{key}_W"], B, reg, rtol, dt, A_dense)
+    assert W.shape == B.shape and W.device.type == dev.type
+    assert set(log[its[-1]]) == {"iter_time", "cum_time", "metrics"}
+    assert set(log[0]["metrics"]["internal_metrics"]) == {"abs_res", "rel_res"}
+
+
+@pytest.mark.parametrize("pname", ["nystrom", "identity"])
+@pytest.mark.parametrize("accel", [True, False])
+def test_linsys_sap_matches_reference_trajectory(dev, prec, pname, accel):
+    g = load_golden(f"sap_{prec}")
+    dt = DTYPES[prec]
+    key = f"{pname}_{'accel' if accel else 'plain'}"
+    X, B, reg = g["X"].to(dev), g["B"].to(dev), float(g["reg"])
+    op = RBFLinOp(X, X, KernelConfig(lengthscale=1.0))
+    pcfg = IdentityConfig() if pname == "identity" else NystromConfig(rank=16, rho=reg, sketch="gauss")
+    cfg = SAPConfig(device=dev, max_iters=40, atol=0.0, rtol=1e-12, precond_config=pcfg, blk_sz=48,
+                    accel=accel, accel_config=SAPAccelConfig(mu=reg, nu=float(g["nu"])) if accel else None)
+    system = LinSys(op, B, reg=reg, A_row_oracle=op.row_oracle, A_blk_oracle=op.blk_oracle)
+    # feed the reference's own draws: blocks, per-step sketches, power-iteration starts
+    import rlaopt_amd.models.linsys as ml
+
+    orig = ml._get_solver
+
+    def patched(model, W_init, solver_config):
+        s = orig(model=model, W_init=W_init, solver_config=solver_config)
+        s.inject_draws(blocks=list(g[f"{key}_blks"]), starts=list(g[f"{key}_v0s"]))
+        return s
+
+    ml._get_solver = patched
+    try:
+        omegas = list(g[f"{key}_omegas"]) if pname == "nystrom" else []
+        with sketches.inject(*omegas):
+            W, log = system.solve(cfg, torch.zeros_like(B), callback_freq=10)
+    finally:
+        ml._get_solver = orig
+    assert sorted(log) == g[f"{key}_iters"].tolist()
+    tol = TOL[dt] if dt == torch.float64 else dict(rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(W.cpu(), g[f"{key}_W"], **tol)
+    rel = torch.stack([log[i]["metrics"]["internal_metrics"]["rel_res"].cpu() for i in sorted(log)])
+    torch.testing.assert_close(rel, g[f"{key}_rel_res"], **tol)
+
+
+@pytest.mark.parametrize("kind", ok.KINDS)
+def test_kernel_operator_protocol(dev, prec, kind):
+    """K@v, K@M, v@K, K.T@v, M@K, row / block oracle (tests/kernels/test_standard.py:186-326)."""
+    from rlaopt_amd import kernels as rk
+
+    g = load_golden(f"kernels_{prec}")
+    dt = DTYPES[prec]
+    X1, X2, ard = g["ragged_X1"].to(dev), g["ragged_X2"].to(dev), g["ragged_ard"].to(dev)
+    K = g[f"ragged_{kind}_ard"]
+    cls = {"rbf": rk.RBFLinOp, "laplace": rk.LaplaceLinOp, "matern12": rk.Matern12LinOp,
+           "matern32": rk.Matern32LinOp, "matern52": rk.Matern52LinOp}[kind]
+    op = cls(X1, X2, KernelConfig(const_scaling=2.0, lengthscale=ard))
+    gen = torch.Generator().manual_seed(0)
+    v, M = torch.randn(23, dtype=dt, generator=gen), torch.randn(23, 2, dtype=dt, generator=gen)
+    u, N = torch.randn(37, dtype=dt, generator=gen), torch.randn(2, 37, dtype=dt, generator=gen)
+    tol = TOL[dt]
+    assert op.shape == (37, 23) and op.dtype == dt and op.device == X1.device
+    torch.testing.assert_close((op @ v.to(dev)).cpu(), K @ v, **tol)
+    torch.testing.assert_close((op @ M.to(dev)).cpu(), K @ M, **tol)
+    torch.testing.assert_close((u.to(dev) @ op).cpu(), u @ K, **tol)
+    torch.testing.assert_close((op.T @ u.to(dev)).cpu(), K.T @ u, **tol)
+    torch.testing.assert_close((N.to(dev) @ op).cpu(), N @ K, **tol)
+    blk = torch.tensor([0, 1, 9])
+    torch.testing.assert_close((op.row_oracle(blk) @ M.to(dev)).cpu(), K[blk] @ M, **tol)
+    sq = cls(X1, X1, KernelConfig(const_scaling=2.0, lengthscale=ard))
+    Ksq = ok.kernel_matrix(kind, g["ragged_X1"], g["ragged_X1"], g["ragged_ard"], 2.0)
+    w = torch.randn(3, dtype=dt, generator=gen)
+    torch.testing.assert_close((sq.blk_oracle(blk) @ w.to(dev)).cpu(), Ksq[blk][:, blk] @ w, **tol)
+    torch.testing.assert_close((sq @ u.to(dev)).cpu(), Ksq @ u, **tol)
+    with pytest.raises(ValueError):
+        op @ torch.zeros(2, 2, 2, dtype=dt, device=dev)
+
+
+@pytest.mark.parametrize("parts", [1, 2, 3])
+def test_distributed_kernel_operator_single_process(dev, prec, parts):
+    """DistributedRBFLinOp inside ONE process (shards visited in turn): full products,
+    transpose, row / block oracles, use_full_kernel=False (tests/kernels/test_distributed.py:
+    153-423).  ``parts`` > 1 reuses the same device for several shards."""
+    from rlaopt_amd.kernels.base import _DistributedKernelLinOp
+
+    dt = DTYPES[prec]
+    gen = torch.Generator().manual_seed(4)
+    n1, n2, d = 41, 29, 4
+    X1 = torch.randn(n1, d, dtype=dt, generator=gen)
+    X2 = torch.randn(n2, d, dtype=dt, generator=gen)
+    K = ok.kernel_matrix("rbf", X1, X2, 1.3, 2.0)
+    cfg = KernelConfig(const_scaling=2.0, lengthscale=1.3)
+
+    class Op(_DistributedKernelLinOp):  # several shards on one device
+        def __init__(self, full=True):
+            _DistributedKernelLinOp.__init__(self, X1.to(dev), X2.to(dev), cfg, {dev}, full, "rbf")
+
+    import rlaopt_amd.kernels.base as kb
+
+    orig = kb._sorted_devices
+    kb._sorted_devices = lambda devices: [dev] * parts
+    try:
+        op = Op()
+        tol = TOL[dt]
+        M = torch.randn(n2, 3, dtype=dt, generator=gen)
+        u = torch.randn(n1, 2, dtype=dt, generator=gen)
+        assert op.shape == (n1, n2) and len(op.devices) == len(ok.row_chunks(n1, parts))
+        with pytest.raises(AttributeError):
+            op.device
+        torch.testing.assert_close((op @ M.to(dev)).cpu(), K @ M, **tol)
+        torch.testing.assert_close((op @ M[:, 0].contiguous().to(dev)).cpu(), K @ M[:, 0], **tol)
+        torch.testing.assert_close((op.T @ u.to(dev)).cpu(), K.T @ u, **tol)
+        torch.testing.assert_close((u.T.contiguous().to(dev) @ op).cpu(), u.T @ K, **tol)
+        blk = torch.tensor([3, 40, 7, 19, 0])
+        torch.testing.assert_close((op.row_oracle(blk) @ M.to(dev)).cpu(), K[blk] @ M, **tol)
+        sqop_X = X1.to(dev)
+
+        class Sq(_DistributedKernelLinOp):
+            def __init__(self, full):
+                _DistributedKernelLinOp.__init__(self, sqop_X, sqop_X, cfg, {dev}, full, "rbf")
+
+        Ksq = ok.kernel_matrix("rbf", X1, X1, 1.3, 2.0)
+        w = torch.randn(5, 2, dtype=dt, generator=gen)
+        for full in (True, False):
+            sq = Sq(full)
+            torch.testing.assert_close((sq.blk_oracle(blk) @ w.to(dev)).cpu(), Ksq[blk][:, blk] @ w, **tol)
+            torch.testing.assert_close((sq.row_oracle(blk) @ u.to(dev)).cpu(), Ksq[blk] @ u, **tol)
+            if not full:
+                with pytest.raises(RuntimeError):
+                    sq @ u.to(dev)
+            sq.shutdown()
+        op.shutdown()
+    finally:
+        kb._sorted_devices = orig
+
+
+def test_generic_linop_and_identity_pcg(dev, prec):
+    """PCG over an opaque user LinOp with the Identity preconditioner (plain CG)."""
+    dt = DTYPES[prec]
+    gen = torch.Generator().manual_seed(8)
+    n = 60
+    G = torch.randn(n, n, dtype=torch.float64, generator=gen)
+    A = (G @ G.T / n + torch.eye(n, dtype=torch.float64)).to(dt)
+    b = torch.randn(n, dtype=dt, generator=gen)
+    Ad = A.to(dev)
+    op = LinOp(dev, torch.Size((n, n)), lambda v: Ad @ v, lambda v: Ad @ v, dtype=dt)
+    system = LinSys(op, b.to(dev), reg=0.5)
+    rtol = 1e-10 if dt == torch.float64 else 1e-5
+    W, log = system.solve(PCGConfig(device=dev, max_iters=200, rtol=rtol), torch.zeros(n, 1, dtype=dt, device=dev), callback_freq=1)
+    want = torch.linalg.solve(A.double() + 0.5 * torch.eye(n, dtype=torch.float64), b.double())
+    assert float((W[:, 0].cpu().double() - want).norm() / want.norm()) < (1e-8 if dt == torch.float64 else 1e-4)
+    assert float(log[max(log)]["metrics"]["internal_metrics"]["rel_res"][0]) <= rtol
+
+
+def test_api_validation_errors(dev):
+    CPU = torch.device("cpu")
+    with pytest.raises(TypeError):
+        KernelConfig(lengthscale=1)  # int, not float
+    with pytest.raises(ValueError):
+        KernelConfig(lengthscale=torch.ones(2, 2))
+    with pytest.raises(TypeError):
+        LinSys("not an operator", torch.zeros(3))
+    with pytest.raises(ValueError):
+        LinSys(torch.eye(3), torch.zeros(3), A_row_oracle=lambda b: None)
+    with pytest.raises(ValueError):
+        SAPConfig(device=CPU, blk_sz=2, accel=True)
+    with pytest.raises(ValueError):
+        SAPAccelConfig(mu=2.0, nu=1.0)
+    with pytest.raises(ValueError):
+        NystromConfig(rank=3, rho=1.0, damping_mode="sometimes")
+    with pytest.raises(TypeError):
+        PCGConfig(device="cpu")
+    with pytest.raises(ValueError):
+        LinOp(CPU, torch.Size((2, 0)), lambda v: v)
+    with pytest.raises(NotImplementedError):
+        LinOp(CPU, torch.Size((2, 2)), lambda v: v).T
+    with pytest.raises(ValueError):
+        RBFLinOp(torch.zeros(3), torch.zeros(3, 2), KernelConfig(lengthscale=1.0))
+    with pytest.raises(TypeError):
+        RBFLinOp(torch.zeros(3, 2), torch.zeros(3, 2), {"lengthscale": 1.0})
+    sysm = LinSys(torch.eye(3, dtype=torch.float64, device=dev), torch.zeros(3, dtype=torch.float64, device=dev))
+    with pytest.raises(ValueError):  # 1-D W_init is refused (the reference silently broadcasts)
+        sysm.solve(PCGConfig(device=dev), torch.zeros(3, dtype=torch.float64, device=dev))

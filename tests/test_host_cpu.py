@@ -1,217 +1,20 @@
 """Host-side logic of the package on CPU, with the oracle injected as compute backend
-(``tests/_oracle_backend.py``): the package's own Nystrom / SkPre / PCG / SAP / LinSys code
-must reproduce the REFERENCE's golden outputs (tests/golden/*.npz)."""
+(``tests/_oracle_backend.py``).  The cases live in ``stack_cases.py``."""
 
 import pytest
 import torch
 
 from _oracle_backend import OracleBackend
-from conftest import DTYPES, TOL, load_golden
-from oracle import kernels as ok
-from rlaopt_amd import sketches
-from rlaopt_amd.kernels import KernelConfig, RBFLinOp
-from rlaopt_amd.linops import LinOp, SymmetricLinOp
-from rlaopt_amd.models import LinSys
 from rlaopt_amd.ops import use_backend
-from rlaopt_amd.preconditioners import IdentityConfig, NystromConfig, SkPreConfig
-from rlaopt_amd.preconditioners.nystrom import Nystrom
-from rlaopt_amd.preconditioners.skpre import SkPre
-from rlaopt_amd.solvers import PCGConfig, SAPAccelConfig, SAPConfig
-
-CPU = torch.device("cpu")
+from stack_cases import *  # noqa: F401,F403
 
 
-def check_pcg_parity(rel, want, W, Wref, B, reg, rtol, dt, A_dense):
-    """What "same trajectory" can mean for CG in floating point:
-
-    * the first logged iterations agree tightly (same algorithm, same inputs);
-    * later the recurrences amplify rounding differences (CG loses orthogonality; two
-      correctly rounded implementations drift by tens of percent mid-solve while converging
-      at the same rate) - the whole history must stay inside a one-logging-window envelope of the reference's, or within the
-      dtype's absolute tolerance (1e-8 / 1e-4) once it is that small;
-    * both solutions met the residual test, so they differ by <= 2 rtol in residual space
-      (checked with 3 rtol; in solution space that is amplified by cond(A + reg I)).
-    The identical iteration count is asserted by the caller."""
-    f64 = dt == torch.float64
-    head = min(3, rel.shape[0])
-    torch.testing.assert_close(rel[:head], want[:head], rtol=1e-6 if f64 else 3e-2, atol=0)
-    atol = 1e-8 if f64 else 1e-4
-    ok_abs = (rel - want).abs() <= atol
-    # envelope: within a factor 2 of the reference's value at the same logged iteration or
-    # one of its two neighbours (i.e. never more than one logging window ahead or behind)
-    T = want.shape[0]
-    nb = torch.stack([want[max(t - 1, 0) : min(t + 2, T)].min(dim=0).values for t in range(T)])
-    nbmax = torch.stack([want[max(t - 1, 0) : min(t + 2, T)].max(dim=0).values for t in range(T)])
-    ok_rel = (rel >= nb / 2) & (rel <= nbmax * 2)
-    assert bool((ok_abs | ok_rel).all()), (rel, want)
-    D = (W - Wref).double()
-    gap = torch.linalg.norm(A_dense.double() @ D + reg * D, dim=0)
-    assert bool((gap / torch.linalg.norm(B.double(), dim=0) <= 3 * rtol).all())
+@pytest.fixture
+def dev():
+    return torch.device("cpu")
 
 
 @pytest.fixture(autouse=True)
 def oracle_backend():
     with use_backend(OracleBackend()):
         yield
-
-
-@pytest.mark.parametrize("case", ["a50", "a300"])
-@pytest.mark.parametrize("sketch", ["gauss", "ortho", "sparse"])
-@pytest.mark.parametrize("mode", ["adaptive", "non_adaptive"])
-def test_nystrom_gram_assembly_matches_reference_svd(prec, case, sketch, mode):
-    g = load_golden(f"nystrom_{prec}")
-    dt = DTYPES[prec]
-    A, x = g[f"{case}_A"], g[f"{case}_x"]
-    key = f"{case}_{sketch}_{mode}"
-    rho0, base = (1.0, 0.5) if case == "a50" else (1e-6, 1e-6)
-    rank = 20 if case == "a50" else 40
-    P = Nystrom(NystromConfig(rank=rank, rho=rho0, sketch=sketch, damping_mode=mode))
-    op = A if case == "a50" else SymmetricLinOp(CPU, A.shape, lambda v: A @ v, lambda v: A @ v, dtype=dt)
-    with sketches.inject(g[f"{key}_Omega"]):
-        P._update(op, CPU)
-    P._update_damping(base)
-    tol = TOL[dt]
-    assert P.U.dtype == dt and P.S.dtype == dt and P.U.shape == (A.shape[0], rank)
-    torch.testing.assert_close(P.S, g[f"{key}_S"], **tol)
-    assert abs(P.config.rho - float(g[f"{key}_rho"])) <= tol["atol"] + tol["rtol"] * abs(float(g[f"{key}_rho"]))
-    torch.testing.assert_close(P.U.T @ P.U, torch.eye(rank, dtype=dt), **tol)
-    torch.testing.assert_close(P @ x, g[f"{key}_Px"], **tol)
-    ref = g[f"{key}_Pinvx"]
-    got = P._inv @ x
-    assert (got - ref).abs().max() <= tol["rtol"] * ref.abs().max() * 10 + tol["atol"]
-    assert got.shape == x.shape
-    # P (P^-1 x) == x  (tests/preconditioners/test_nystrom.py:209-257)
-    if case == "a50":  # well-conditioned P (rho = 1) like the reference's round-trip test
-        back = P @ got
-        assert (back - x).abs().max() <= 50 * tol["rtol"] * x.abs().max() + tol["atol"]
-
-
-def test_skpre_matches_reference(prec):
-    g = load_golden(f"skpre_{prec}")
-    dt = DTYPES[prec]
-    P = SkPre(SkPreConfig(sketch_size=96, rho=1e-3, sketch="gauss"))
-    with sketches.inject(g["Omega"]):
-        P._update(g["A"], CPU)
-    tol = TOL[dt] if dt == torch.float64 else dict(rtol=1e-2, atol=1e-4)
-    torch.testing.assert_close(P.L, g["L"], **tol)
-    torch.testing.assert_close(P @ g["x"], g["Px"], **tol)
-    torch.testing.assert_close(P._inv @ g["x"], g["Pinvx"], **tol)
-
-
-@pytest.mark.parametrize("case", ["dense", "krr"])
-@pytest.mark.parametrize("k", [1, 3])
-@pytest.mark.parametrize("sketch", ["gauss", "ortho"])
-def test_linsys_pcg_matches_reference_history(prec, case, k, sketch):
-    g = load_golden(f"pcg_{prec}")
-    dt = DTYPES[prec]
-    key = f"{case}_k{k}_{sketch}"
-    B, reg, rtol = g[f"{key}_B"], float(g[f"{key}_reg"]), float(g[f"{key}_rtol"])
-    if case == "dense":
-        A = g["dense_A"]
-    else:
-        A = RBFLinOp(g["krr_X"], g["krr_X"], KernelConfig(lengthscale=1.0))
-    cfg = PCGConfig(device=CPU, max_iters=300, atol=0.0, rtol=rtol,
-                    precond_config=NystromConfig(rank=48, rho=reg, sketch=sketch))
-    system = LinSys(A, B if k > 1 else B[:, 0], reg=reg)
-    with sketches.inject(g[f"{key}_Omega"]):
-        W, log = system.solve(cfg, torch.zeros_like(B), callback_freq=5)
-    its = sorted(log)
-    assert its == g[f"{key}_iters"].tolist()
-    rel = torch.stack([log[i]["metrics"]["internal_metrics"]["rel_res"] for i in its])
-    want = g[f"{key}_rel_res"]
-    check_pcg_parity(rel, want, W, g[f"{key}_W"], B, reg, rtol, dt,
-                     g["dense_A"] if case == "dense" else ok.kernel_matrix("rbf", g["krr_X"], g["krr_X"], 1.0))
-    assert set(log[its[-1]]) == {"iter_time", "cum_time", "metrics"}
-
-
-@pytest.mark.parametrize("pname", ["nystrom", "identity"])
-@pytest.mark.parametrize("accel", [True, False])
-def test_linsys_sap_matches_reference_trajectory(prec, pname, accel):
-    g = load_golden(f"sap_{prec}")
-    dt = DTYPES[prec]
-    key = f"{pname}_{'accel' if accel else 'plain'}"
-    X, B, reg = g["X"], g["B"], float(g["reg"])
-    op = RBFLinOp(X, X, KernelConfig(lengthscale=1.0))
-    pcfg = IdentityConfig() if pname == "identity" else NystromConfig(rank=16, rho=reg, sketch="gauss")
-    cfg = SAPConfig(device=CPU, max_iters=40, atol=0.0, rtol=1e-12, precond_config=pcfg, blk_sz=48,
-                    accel=accel, accel_config=SAPAccelConfig(mu=reg, nu=float(g["nu"])) if accel else None)
-    system = LinSys(op, B, reg=reg, A_row_oracle=op.row_oracle, A_blk_oracle=op.blk_oracle)
-    # feed the reference's own draws: blocks, per-step sketches, power-iteration starts
-    from rlaopt_amd.solvers import factory as sf
-
-    made = {}
-    orig = sf._get_solver
-
-    def patched(model, W_init, solver_config):
-        s = orig(model=model, W_init=W_init, solver_config=solver_config)
-        s.inject_draws(blocks=list(g[f"{key}_blks"]), starts=list(g[f"{key}_v0s"]))
-        made["s"] = s
-        return s
-
-    import rlaopt_amd.models.linsys as ml
-
-    ml._get_solver = patched
-    try:
-        omegas = list(g[f"{key}_omegas"]) if pname == "nystrom" else []
-        with sketches.inject(*omegas):
-            W, log = system.solve(cfg, torch.zeros_like(B), callback_freq=10)
-    finally:
-        ml._get_solver = orig
-    assert sorted(log) == g[f"{key}_iters"].tolist()
-    tol = TOL[dt] if dt == torch.float64 else dict(rtol=1e-3, atol=1e-4)
-    torch.testing.assert_close(W, g[f"{key}_W"], **tol)
-    rel = torch.stack([log[i]["metrics"]["internal_metrics"]["rel_res"] for i in sorted(log)])
-    torch.testing.assert_close(rel, g[f"{key}_rel_res"], **tol)
-
-
-def test_kernel_operator_protocol(prec):
-    """K@v, K@M, v@K, K.T@v, M@K, row / block oracle (tests/kernels/test_standard.py:186-326)."""
-    g = load_golden(f"kernels_{prec}")
-    dt = DTYPES[prec]
-    X1, X2, ard = g["ragged_X1"], g["ragged_X2"], g["ragged_ard"]
-    K = g["ragged_rbf_ard"]
-    op = RBFLinOp(X1, X2, KernelConfig(const_scaling=2.0, lengthscale=ard))
-    gen = torch.Generator().manual_seed(0)
-    v, M = torch.randn(23, dtype=dt, generator=gen), torch.randn(23, 2, dtype=dt, generator=gen)
-    u, N = torch.randn(37, dtype=dt, generator=gen), torch.randn(2, 37, dtype=dt, generator=gen)
-    tol = TOL[dt]
-    assert op.shape == (37, 23) and op.dtype == dt and op.device == CPU
-    torch.testing.assert_close(op @ v, K @ v, **tol)
-    torch.testing.assert_close(op @ M, K @ M, **tol)
-    torch.testing.assert_close(u @ op, u @ K, **tol)
-    torch.testing.assert_close(op.T @ u, K.T @ u, **tol)
-    torch.testing.assert_close(N @ op, N @ K, **tol)
-    blk = torch.tensor([0, 1, 9])
-    torch.testing.assert_close(op.row_oracle(blk) @ M, K[blk] @ M, **tol)
-    sq = RBFLinOp(X1, X1, KernelConfig(const_scaling=2.0, lengthscale=ard))
-    Ksq = ok.kernel_matrix("rbf", X1, X1, ard, 2.0)
-    w = torch.randn(3, dtype=dt, generator=gen)
-    torch.testing.assert_close(sq.blk_oracle(blk) @ w, Ksq[blk][:, blk] @ w, **tol)
-    with pytest.raises(ValueError):
-        op @ torch.zeros(2, 2, 2, dtype=dt)
-
-
-def test_api_validation_errors():
-    with pytest.raises(TypeError):
-        KernelConfig(lengthscale=1)  # int, not float
-    with pytest.raises(ValueError):
-        KernelConfig(lengthscale=torch.ones(2, 2))
-    with pytest.raises(TypeError):
-        LinSys("not an operator", torch.zeros(3))
-    with pytest.raises(ValueError):
-        LinSys(torch.eye(3), torch.zeros(3), A_row_oracle=lambda b: None)
-    with pytest.raises(ValueError):
-        SAPConfig(device=CPU, blk_sz=2, accel=True)
-    with pytest.raises(ValueError):
-        SAPAccelConfig(mu=2.0, nu=1.0)
-    with pytest.raises(ValueError):
-        NystromConfig(rank=3, rho=1.0, damping_mode="sometimes")
-    with pytest.raises(TypeError):
-        PCGConfig(device="cpu")
-    with pytest.raises(ValueError):
-        LinOp(CPU, torch.Size((2, 0)), lambda v: v)
-    with pytest.raises(NotImplementedError):
-        LinOp(CPU, torch.Size((2, 2)), lambda v: v).T
-    sysm = LinSys(torch.eye(3, dtype=torch.float64), torch.zeros(3, dtype=torch.float64))
-    with pytest.raises(ValueError):  # 1-D W_init is refused (the reference silently broadcasts)
-        sysm.solve(PCGConfig(device=CPU), torch.zeros(3, dtype=torch.float64))
