@@ -76,7 +76,8 @@ class _KernelBlock:
     def matmat(self, x, diag_shift=0.0, row0=0, alpha=1.0, beta=0.0, C=None):
         be = get_backend()
         if self.materialised:
-            return be.matmat(self.K, x, alpha=alpha, beta=beta, C=C, diag_shift=diag_shift, row0=row0)
+            return be.matmat(self.K, x, alpha=alpha, beta=beta, C=C, diag_shift=diag_shift, row0=row0,
+                             tag="kernel_shard_product")
         y = be.kernel_matmat(self.kind, self.A1, self.A2, self.config.lengthscale, x, scale=self.scale)
         if diag_shift != 0.0:
             y = y + diag_shift * x[row0 : row0 + y.shape[0]]

@@ -192,8 +192,9 @@ class HipBackend:
         return out[:, 0] if squeeze else out
 
     # -- dense products ----------------------------------------------------------------
-    def matmat(self, A, V, alpha=1.0, beta=0.0, C=None, diag_shift=0.0, row0=0):
-        """alpha * A @ V + beta * C + diag_shift * V[row0 : row0 + m]."""
+    def matmat(self, A, V, alpha=1.0, beta=0.0, C=None, diag_shift=0.0, row0=0, tag=None):
+        """alpha * A @ V + beta * C + diag_shift * V[row0 : row0 + m].  ``tag`` names the
+        launch in the optional timing table."""
         dev = _req(A, V, C)
         V2, squeeze = _as2d(V)
         if A.shape[1] != V2.shape[0]:
@@ -213,7 +214,7 @@ class HipBackend:
             nbytes = self._lib.rk_matmat_skinny_ws_bytes(_dt(A), m, n, k)
             ws, wsn = self._workspace(dev, nbytes)
             algo = (m * n + n * k + m * k) * A.element_size()
-            with self._timed("rk_matmat_skinny" if m * n >= (1 << 24) else "rk_matmat_skinny(small)", dev, algo):
+            with self._timed(tag or "rk_matmat_skinny(untagged)", dev, algo):
                 rc = self._lib.rk_matmat_skinny(
                     _dt(A), _ptr(A), m, n, lda, _ptr(V2), k, ldv, float(alpha), float(beta),
                     _ptr(C2), (ldc if C2 is not None else k), float(diag_shift), int(row0),

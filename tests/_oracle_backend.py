@@ -26,7 +26,7 @@ class OracleBackend:
     def kernel_matmat(self, kind, X1, X2, lengthscale, V, scale=1.0, idx1=None, idx2=None):
         return ok.kernel_matmat(kind, X1, X2, lengthscale, V, scale, idx1=idx1, idx2=idx2)
 
-    def matmat(self, A, V, alpha=1.0, beta=0.0, C=None, diag_shift=0.0, row0=0):
+    def matmat(self, A, V, alpha=1.0, beta=0.0, C=None, diag_shift=0.0, row0=0, tag=None):
         V2, sq = _two_d(V)
         Y = alpha * (A @ V2)
         if beta != 0.0:

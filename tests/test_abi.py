@@ -1,0 +1,75 @@
+"""The C-ABI boundary without a GPU: librk_hip.so loads, exports every symbol that
+include/rk.h declares (and nothing the binding expects is missing), reports its ABI version,
+and the product refuses CPU tensors instead of falling back.  No compute calls here."""
+
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rk.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rk_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    names = declared_symbols()
+    for must in ("rk_kernel_materialize", "rk_kernel_matmat", "rk_matmat_skinny", "rk_matmat_skinny_t",
+                 "rk_gemm", "rk_gram_tn", "rk_pcg_update_wr", "rk_pcg_update_p", "rk_small_solve",
+                 "rk_randn", "rk_last_error", "rk_abi_version"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from rlaopt_amd import _lib
+
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"{name} declared in include/rk.h but not exported"
+    assert sorted(_lib.SIGNATURES) == declared_symbols()  # binding and header agree
+    bound = _lib.load()
+    assert bound.rk_abi_version() == _lib.ABI_VERSION
+    assert bound.rk_last_error() == b""
+
+
+def test_argument_validation_needs_no_gpu():
+    """Bad arguments are rejected by the host-side checks before any launch."""
+    from rlaopt_amd import _lib
+
+    lib = _lib.load()
+    rc = lib.rk_matmat_skinny(0, None, 4, 4, 4, None, 1, 1, 1.0, 0.0, None, 1, 0.0, 0, None, 1, None, 0, None)
+    assert rc == -1 and b"null pointer" in lib.rk_last_error()
+    rc = lib.rk_small_solve(17, 1, None, None, None, None)
+    assert rc == -1
+    assert lib.rk_matmat_skinny_ws_bytes(0, 25000, 200000, 1) > 0  # column-segment partials
+    assert lib.rk_matmat_skinny_ws_bytes(0, 200000, 64, 1) == 0
+    with pytest.raises(ValueError):
+        _lib.check(-1, "x")
+    with pytest.raises(RuntimeError):
+        _lib.check(-2, "x")
+
+
+def test_product_refuses_cpu_tensors():
+    from rlaopt_amd.ops import HipBackend
+
+    be = HipBackend()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        be.matmat(torch.zeros(4, 4), torch.zeros(4, 1))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        be.kernel_materialize("rbf", torch.zeros(4, 2), torch.zeros(4, 2), 1.0)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: no module of the package may reference it."""
+    pkg = os.path.join(ROOT, "rlaopt_amd")
+    for dirpath, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
