@@ -83,6 +83,23 @@ def cpu_baseline(X, n, budget_s=12.0):
     }
 
 
+def committed_traffic(world, n):
+    """HBM bytes per shard-product launch from the committed PMC summary (profiles/*_traffic.json,
+    written by tools/summarize_profile.py from separate rocprofv3 --pmc passes) when one exists
+    for this exact workload; None otherwise."""
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if rec.get("n_gpus") == world and f"n={n} " in rec.get("workload", ""):
+            best = rec
+    return None if best is None else best["hbm_bytes_per_launch"]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,7 +240,7 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": committed_traffic(world, n),
                 "bytes_per_launch": mv["bytes_per_launch"],
                 "avg_launch_ms": mv["avg_ms"],
                 "launches": mv["launches"],

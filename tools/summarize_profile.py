@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output of `tools/gpu_round.sh <tag>` into committed summaries:
+
+  profiles/<tag>_kernel_stats.csv      per-kernel totals of the bench run (--kernel-trace --stats)
+  profiles/<tag>_summary.md            readable table + HBM traffic of the dominant kernel
+  profiles/<tag>_traffic.json          machine-readable HBM bytes per launch (bench.py reads it)
+
+HBM traffic follows MI355X_MICROARCH.md "HBM": bytes = (FETCH_SIZE + WRITE_SIZE) * 1024 with the
+gfx950 correction FETCH_SIZE x 2 for wide coalesced streaming reads; the two counters are
+collected in separate passes."""
+import csv
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"
+dst = "profiles"
+os.makedirs(dst, exist_ok=True)
+stats = f"{src}/{tag}_prof/{tag}_kernel_stats.csv"
+shutil.copy(stats, f"{dst}/{tag}_kernel_stats.csv")
+shutil.copy(f"{src}/{tag}_bench_under_rocprof.log", f"{dst}/{tag}_bench_under_rocprof.log")
+shutil.copy(f"{src}/{tag}_bench_n1.log", f"{dst}/{tag}_bench_n1.log")
+rows = list(csv.DictReader(open(stats)))
+
+
+def pmc(kind):
+    path = f"{src}/{tag}_pmc_{kind}/{tag}_counter_collection.csv"
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+            if "skinny_nn_kernel" in r["Kernel_Name"] and int(r["Grid_Size"]) > 1_000_000]
+    big = [v for v in vals if v > 0.5 * max(vals)]  # the n_loc x n launches, not the U @ t ones
+    return sum(big) / len(big), len(big)
+
+
+trace = list(csv.DictReader(open(f"{src}/{tag}_prof/{tag}_kernel_trace.csv")))
+shard = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in trace
+         if "skinny_nn_kernel" in r["Kernel_Name"] and int(r["Grid_Size_Y"]) > 1]
+shard_avg_ms = sum(shard) / len(shard)
+fetch, nf = pmc("fetch")
+write, nw = pmc("write")
+traffic = (2.0 * fetch + write) * 1024.0
+bench = json.loads([l for l in open(f"{src}/{tag}_bench_n1.log") if l.startswith("{")][-1])
+algo = bench["roofline"]["bytes_per_launch"]
+out = {
+    "tag": tag, "kernel": "skinny_nn_kernel<float,1,8,true>", "launches_sampled": [nf, nw],
+    "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "fetch_correction": 2.0,
+    "hbm_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": algo,
+    "traffic_over_algorithmic": traffic / algo,
+    "workload": bench["config"]["workload"], "n_gpus": bench["n_gpus"],
+    "rocprof_shard_product_avg_ms": shard_avg_ms, "rocprof_shard_product_launches": len(shard),
+}
+json.dump(out, open(f"{dst}/{tag}_traffic.json", "w"), indent=1)
+with open(f"{dst}/{tag}_summary.md", "w") as f:
+    f.write(f"# rocprofv3 summary `{tag}` - `bench.py --steps 20 --warmup 5` on one MI355X\n\n")
+    f.write(f"bench line: value {bench['value']:.2f} iter/s, {bench['ms_per_step']:.2f} ms/step; "
+            f"roofline achieved {bench['roofline']['achieved']:.0f} GB/s "
+            f"({100 * bench['roofline']['frac']:.1f} % of 8000), avg launch "
+            f"{bench['roofline']['avg_launch_ms']:.3f} ms (HIP events in bench.py)\n\n")
+    f.write("## kernel stats (rocprofv3 --kernel-trace --stats, whole process incl. setup)\n\n")
+    f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+    for r in rows[:16]:
+        f.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | "
+                f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
+    f.write(f"\nThe `skinny_nn_kernel` row mixes the n_loc x n shard product with the small U @ t "
+            f"launches of the Nystrom apply (same instantiation). Shard-product launches alone "
+            f"(kernel trace rows with Grid_Size_Y > 1, i.e. column-segmented): **{len(shard)} launches, "
+            f"average {shard_avg_ms:.3f} ms** (rocprofv3) vs {bench['roofline']['avg_launch_ms']:.3f} ms "
+            f"(HIP events inside bench.py, un-profiled run).\n\n")
+    f.write("## HBM traffic of the shard product (separate --pmc passes)\n\n")
+    f.write(f"FETCH_SIZE = {fetch:.0f} KB, WRITE_SIZE = {write:.0f} KB per launch -> "
+            f"(2 x FETCH + WRITE) x 1024 = {traffic / 1e9:.2f} GB vs algorithmic {algo / 1e9:.2f} GB "
+            f"(ratio {traffic / algo:.3f}): the shard is read exactly once.\n")
+print(json.dumps(out))
