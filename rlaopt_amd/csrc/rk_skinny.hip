@@ -135,6 +135,131 @@ skinny_nn_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Y = A V for 5 <= k <= 16: the V slice of each column step is shared by the 4 waves of the
+// workgroup through LDS (rhs-major, so a lane's 4 columns of one right-hand side are one
+// ds_read_b128) instead of being re-read k times per lane from L2.  Per column step a
+// workgroup moves 4 R KiB of A against one 1 x k KiB V slice; the next slice and the next A
+// rows are fetched into registers before the FMAs of the current step (one barrier per step).
+// ------------------------------------------------------------------------------------------
+template <typename T, int K, int R>
+__global__ void __launch_bounds__(256)
+skinny_nn_lds_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
+                     const T* __restrict__ V, int64_t ldv, T* __restrict__ part, int64_t seg_cols,
+                     T alpha, T beta, const T* __restrict__ C, int64_t ldc, T shift, int64_t row0,
+                     T* __restrict__ Y, int64_t ldy, int vecA) {
+    using V16 = typename Vec16<T>::type;
+    constexpr int VW = Vec16<T>::N;
+    constexpr int STEP = kWave * VW;
+    constexpr int LDV = STEP + 4;            // 16-B aligned rows, <= 2-way store conflicts
+    constexpr int NST = (STEP * K + 255) / 256;  // V elements staged per thread per step
+    __shared__ T vs[2][K][LDV];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * R;
+    const int64_t c_lo = (int64_t)blockIdx.y * seg_cols;
+    const int64_t c_hi = (c_lo + seg_cols < n) ? c_lo + seg_cols : n;
+
+    const T* arow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int64_t row = r0 + r;
+        if (row > m - 1) row = m - 1;  // clamp (all waves must reach the barriers)
+        arow[r] = A + row * lda;
+    }
+    T acc[R][K];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < K; ++c) acc[r][c] = T(0);
+
+    T sreg[NST];
+    auto fetch_v = [&](int64_t jb) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int e = threadIdx.x + u * 256;
+            const int col = e / K, c = e - col * K;
+            const int64_t j = jb + col;
+            sreg[u] = (e < STEP * K && j < c_hi) ? V[j * ldv + c] : T(0);
+        }
+    };
+    auto store_v = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int e = threadIdx.x + u * 256;
+            const int col = e / K, c = e - col * K;
+            if (e < STEP * K) vs[buf][c][col] = sreg[u];
+        }
+    };
+    auto load_a = [&](V16 dst[R], int64_t jb) {
+        const int64_t j = jb + lane * VW;
+        if (vecA && j + VW <= c_hi) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) dst[r] = *reinterpret_cast<const V16*>(arow[r] + j);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                T* de = reinterpret_cast<T*>(&dst[r]);
+#pragma unroll
+                for (int q = 0; q < VW; ++q) de[q] = (j + q < c_hi) ? arow[r][j + q] : T(0);
+            }
+        }
+    };
+
+    V16 cur[R], nxt[R];
+    fetch_v(c_lo);
+    store_v(0);
+    load_a(cur, c_lo);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t jb = c_lo; jb < c_hi; jb += STEP) {
+        const bool more = jb + STEP < c_hi;  // uniform over the workgroup
+        if (more) {
+            fetch_v(jb + STEP);
+            load_a(nxt, jb + STEP);
+        }
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+            const V16 vq = *reinterpret_cast<const V16*>(&vs[buf][c][lane * VW]);
+            const T* ve = reinterpret_cast<const T*>(&vq);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const T* ae = reinterpret_cast<const T*>(&cur[r]);
+#pragma unroll
+                for (int q = 0; q < VW; ++q) acc[r][c] += ae[q] * ve[q];
+            }
+        }
+        if (more) store_v(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+#pragma unroll
+        for (int r = 0; r < R; ++r) cur[r] = nxt[r];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < K; ++c) acc[r][c] = wave_sum(acc[r][c]);
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t row = r0 + r;
+            if (row < m) {
+#pragma unroll
+                for (int c = 0; c < K; ++c) {
+                    if (part != nullptr) {
+                        part[((int64_t)blockIdx.y * m + row) * K + c] = acc[r][c];
+                    } else {
+                        T y = alpha * acc[r][c];
+                        if (beta != T(0)) y += beta * C[row * ldc + c];
+                        if (shift != T(0)) y += shift * V[(row0 + row) * ldv + c];
+                        Y[row * ldy + c] = y;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Y[i][c] = alpha * sum_s part[s][i][c] + beta * C[i][c] + shift * V[row0+i][c]
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -404,7 +529,8 @@ struct NNPlan {
     int64_t seg_cols;  // multiple of the wave step
 };
 
-static int rows_per_wave(int64_t k) { return k <= 2 ? 8 : (k <= 4 ? 4 : (k <= 8 ? 2 : 1)); }
+// k <= 4: register kernel (V slice in registers); k >= 5: LDS-shared V slice
+static int rows_per_wave(int64_t k) { return k <= 2 ? 8 : (k <= 4 ? 4 : (k <= 8 ? 8 : 4)); }
 
 static NNPlan plan_nn(int dtype, int64_t m, int64_t n, int64_t k) {
     const int64_t step = (dtype == RK_F32) ? 256 : 128;
@@ -456,15 +582,23 @@ static int matmat_skinny_impl(const T* A, int64_t m, int64_t n, int64_t lda, con
         launch_nn<T, KK, RR>(vec, grid, st, A, m, n, lda, V, ldv, part, p.seg_cols, (T)alpha,   \
                              (T)beta, C, ldc, (T)shift, row0, Y, ldy);                          \
         break;
+#define RK_NN_LDS_CASE(KK, RR)                                                                   \
+    case KK:                                                                                     \
+        hipLaunchKernelGGL((skinny_nn_lds_kernel<T, KK, RR>), grid, dim3(256), 0, st, A, m, n,   \
+                           lda, V, ldv, part, p.seg_cols, (T)alpha, (T)beta, C, ldc, (T)shift,   \
+                           row0, Y, ldy, vecA);                                                  \
+        break;
+    const int vecA = aligned16(A) && (lda % VW == 0);
     switch (k) {
-        RK_NN_CASE(1, 8) RK_NN_CASE(2, 8) RK_NN_CASE(3, 4) RK_NN_CASE(4, 4) RK_NN_CASE(5, 2)
-        RK_NN_CASE(6, 2) RK_NN_CASE(7, 2) RK_NN_CASE(8, 2) RK_NN_CASE(9, 1) RK_NN_CASE(10, 1)
-        RK_NN_CASE(11, 1) RK_NN_CASE(12, 1) RK_NN_CASE(13, 1) RK_NN_CASE(14, 1)
-        RK_NN_CASE(15, 1) RK_NN_CASE(16, 1)
+        RK_NN_CASE(1, 8) RK_NN_CASE(2, 8) RK_NN_CASE(3, 4) RK_NN_CASE(4, 4)
+        RK_NN_LDS_CASE(5, 8) RK_NN_LDS_CASE(6, 8) RK_NN_LDS_CASE(7, 8) RK_NN_LDS_CASE(8, 8)
+        RK_NN_LDS_CASE(9, 4) RK_NN_LDS_CASE(10, 4) RK_NN_LDS_CASE(11, 4) RK_NN_LDS_CASE(12, 4)
+        RK_NN_LDS_CASE(13, 4) RK_NN_LDS_CASE(14, 4) RK_NN_LDS_CASE(15, 4) RK_NN_LDS_CASE(16, 4)
         default:
             set_error("rk_matmat_skinny: k=%lld outside [1,16]", (long long)k);
             return RK_ERR_INVALID;
     }
+#undef RK_NN_LDS_CASE
 #undef RK_NN_CASE
     int rc = launch_status("rk_matmat_skinny");
     if (rc != RK_OK) return rc;

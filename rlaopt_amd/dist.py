@@ -20,8 +20,26 @@ import torch
 import torch.distributed as td
 
 
+import os
+
+
 def initialized() -> bool:
     return td.is_available() and td.is_initialized()
+
+
+def spmd_active(group=None) -> bool:
+    """True when operators should use the one-rank-per-shard layout: a process group with more
+    than one rank, or any group when ``RK_FORCE_SPMD=1`` (lets a single-rank NCCL group drive
+    the collective code path on a one-GPU box)."""
+    if not initialized():
+        return False
+    return td.get_world_size(group) > 1 or os.environ.get("RK_FORCE_SPMD", "0") == "1"
+
+
+def _host_staged(t: torch.Tensor, group) -> bool:
+    # gloo (the CPU test backend) cannot move device buffers: stage through the host.
+    # nccl (= RCCL) takes device pointers directly - the production path.
+    return t.is_cuda and td.get_backend(group) == "gloo"
 
 
 def world(group=None) -> tuple[int, int]:
@@ -48,8 +66,13 @@ def my_rows(n: int, group=None) -> tuple[int, int]:
 
 def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     """In-place sum over ranks (no-op without a group)."""
-    if initialized() and td.get_world_size(group) > 1:
-        td.all_reduce(t, op=td.ReduceOp.SUM, group=group)
+    if spmd_active(group):
+        if _host_staged(t, group):
+            h = t.cpu()
+            td.all_reduce(h, op=td.ReduceOp.SUM, group=group)
+            t.copy_(h)
+        else:
+            td.all_reduce(t, op=td.ReduceOp.SUM, group=group)
     return t
 
 
@@ -65,7 +88,7 @@ def all_gather_rows(local: torch.Tensor, sizes, group=None) -> torch.Tensor:
     ``row_chunks`` partition of n rows).  Blocks are padded to the tallest one so that a
     single ``all_gather_into_tensor`` moves everything."""
     rank, size = world(group)
-    if size == 1:
+    if not spmd_active(group):
         return local
     if isinstance(sizes, int):
         sizes = chunk_sizes(sizes, group)
@@ -81,8 +104,13 @@ def all_gather_rows(local: torch.Tensor, sizes, group=None) -> torch.Tensor:
         pad = torch.zeros((step, k), dtype=loc.dtype, device=loc.device)
         pad[: loc.shape[0]] = loc
         loc = pad
-    out = torch.empty((size * step, k), dtype=loc.dtype, device=loc.device)
-    td.all_gather_into_tensor(out, loc.contiguous(), group=group)
+    if _host_staged(loc, group):
+        host = torch.empty((size * step, k), dtype=loc.dtype)
+        td.all_gather_into_tensor(host, loc.cpu().contiguous(), group=group)
+        out = host.to(loc.device)
+    else:
+        out = torch.empty((size * step, k), dtype=loc.dtype, device=loc.device)
+        td.all_gather_into_tensor(out, loc.contiguous(), group=group)
     total = sum(sizes)
     if _tail_only(sizes, step):  # padding only behind the last non-empty block: one slice
         out = out[:total]
@@ -106,7 +134,7 @@ def _tail_only(sizes, step):
 
 def broadcast_object(obj, src: int = 0, group=None):
     """Small Python object from ``src`` to every rank (e.g. an RNG seed)."""
-    if not initialized() or td.get_world_size(group) == 1:
+    if not spmd_active(group):
         return obj
     box = [obj]
     td.broadcast_object_list(box, src=src, group=group)

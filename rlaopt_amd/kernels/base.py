@@ -210,7 +210,7 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
         self._initialize_scaling(getattr(kernel_config, "const_scaling", 1.0))
         devs = _sorted_devices(devices)
         rank, size = _dist.world(group)
-        spmd = size > 1
+        spmd = _dist.spmd_active(group)
         parts = size if spmd else len(devs)
         n1, n2 = A1.shape[0], A2.shape[0]
         # base.py:297-302: torch.chunk partition of the rows of A1 (operator) and A2 (oracle)

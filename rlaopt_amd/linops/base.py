@@ -114,7 +114,7 @@ class _BaseDistributedLinOp(_BaseLinOp):
         self._distribution_mode = _DistributionMode._from_str(distribution_mode, "distribution_mode")
         self._group = group
         rank, size = _dist.world(group)
-        self._spmd = (size > 1) if spmd is None else bool(spmd)
+        self._spmd = _dist.spmd_active(group) if spmd is None else bool(spmd)
         if self._spmd and len(A) > size:
             raise ValueError(f"{len(A)} shards but only {size} ranks in the process group")
         self._rank = rank

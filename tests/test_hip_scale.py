@@ -119,7 +119,8 @@ def test_fullsize_fused_product_properties(be, full_problem):
     #     gather agrees with slicing
     bounds = [(i * 25000, (i + 1) * 25000) for i in range(8)]
     part = be.kernel_matmat("rbf", Xd[bounds[3][0] : bounds[3][1]], Xd, 1.0, vd)
-    assert torch.equal(part, Kv[bounds[3][0] : bounds[3][1]])
+    whole = Kv[bounds[3][0] : bounds[3][1]]  # (column-segment plans differ: not bitwise equal)
+    assert float((part - whole).norm() / whole.norm()) < 1e-5
     idx = torch.arange(bounds[3][0], bounds[3][0] + 4096, device=DEV)
     gathered = be.kernel_matmat("rbf", Xd, Xd, 1.0, vd, idx1=idx)
     assert float((gathered - Kv[idx]).norm() / Kv[idx].norm()) < 1e-6
