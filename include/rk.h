@@ -146,6 +146,12 @@ int rk_pcg_update_wr(int dtype, int64_t n, int64_t k, void* W, int64_t ldw, void
 /* P = Z + P @ beta                            (rlaopt/solvers/pcg.py:82-83) */
 int rk_pcg_update_p(int dtype, int64_t n, int64_t k, void* P, int64_t ldp,
                     const void* Z, int64_t ldz, const double* beta, void* stream);
+/* Y[:, c] = a[c] * X[:, c] + b[c] * Y[:, c]  (n x k, any k >= 1) with per-column
+ * coefficients in device FLOAT64 arrays (a == NULL means 1, b == NULL means 0: Y is then
+ * write-only).  The column-scaled updates of the LSQR recurrences, kept on the device so
+ * the iteration never reads a scalar back (no reference counterpart: SURVEY 8a row a14). */
+int rk_axpby_cols(int dtype, int64_t n, int64_t k, const void* X, int64_t ldx, const double* a,
+                  void* Y, int64_t ldy, const double* b, void* stream);
 /* X = A^-1 B for k x k A and k x nrhs B (FLOAT64, device), LU with partial pivoting,
  * k <= 16, nrhs <= 16 (torch.linalg.solve at rlaopt/solvers/pcg.py:61,80). A and B are
  * not modified; X may alias B. */

@@ -66,6 +66,9 @@ SIGNATURES = {
     "rk_pcg_update_p": (
         c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]
     ),
+    "rk_axpby_cols": (
+        c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
+    ),
     "rk_small_solve": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rk_randn": (
         c_int, [c_int, c_void_p, c_int64, c_int64, c_int64, c_uint64, c_uint64, c_double, c_void_p]

@@ -424,6 +424,21 @@ pcg_update_p_kernel(int64_t n, int k, T* __restrict__ P, int64_t ldp, const T* _
     }
 }
 
+// Y[:, c] = a[c] * X[:, c] + b[c] * Y[:, c] with device-resident float64 coefficients
+template <typename T>
+__global__ void __launch_bounds__(256)
+axpby_cols_kernel(int64_t n, int k, const T* __restrict__ X, int64_t ldx,
+                  const double* __restrict__ a, T* __restrict__ Y, int64_t ldy,
+                  const double* __restrict__ b) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * k) return;
+    const int64_t i = e / k;
+    const int c = (int)(e - i * k);
+    T y = (a ? (T)a[c] : T(1)) * X[i * ldx + c];
+    if (b) y += (T)b[c] * Y[i * ldy + c];
+    Y[i * ldy + c] = y;
+}
+
 // Gaussian elimination with partial pivoting on the augmented matrix [A | B] in LDS.
 __global__ void __launch_bounds__(512)
 small_solve_kernel(int k, int nrhs, const double* __restrict__ A, const double* __restrict__ B,
@@ -782,6 +797,23 @@ extern "C" int rk_pcg_update_p(int dtype, int64_t n, int64_t k, void* P, int64_t
         hipLaunchKernelGGL((pcg_update_p_kernel<double>), grid, dim3(256), 0, st, n, (int)k,
                            (double*)P, ldp, (const double*)Z, ldz, beta);
     return launch_status("rk_pcg_update_p");
+}
+
+extern "C" int rk_axpby_cols(int dtype, int64_t n, int64_t k, const void* X, int64_t ldx,
+                             const double* a, void* Y, int64_t ldy, const double* b, void* stream) {
+    clear_error();
+    RK_REQUIRE(dtype == RK_F32 || dtype == RK_F64, "rk_axpby_cols: bad dtype %d", dtype);
+    RK_REQUIRE(X && Y, "rk_axpby_cols: null pointer");
+    RK_REQUIRE(n > 0 && k >= 1 && ldx >= k && ldy >= k, "rk_axpby_cols: bad sizes");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)ceil_div(n * k, 256));
+    if (dtype == RK_F32)
+        hipLaunchKernelGGL((axpby_cols_kernel<float>), grid, dim3(256), 0, st, n, (int)k,
+                           (const float*)X, ldx, a, (float*)Y, ldy, b);
+    else
+        hipLaunchKernelGGL((axpby_cols_kernel<double>), grid, dim3(256), 0, st, n, (int)k,
+                           (const double*)X, ldx, a, (double*)Y, ldy, b);
+    return launch_status("rk_axpby_cols");
 }
 
 extern "C" int rk_small_solve(int64_t k, int64_t nrhs, const double* A, const double* B, double* X,

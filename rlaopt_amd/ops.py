@@ -332,6 +332,20 @@ class HipBackend:
         )
         _lib.check(rc, "rk_pcg_update_p")
 
+    def axpby_cols(self, X, a, Y, b=None):
+        """Y[:, c] = a[c] * X[:, c] + b[c] * Y[:, c] in place; a / b float64 device vectors or None."""
+        dev = _req(X, Y, a, b)
+        if X.shape != Y.shape or X.dtype != Y.dtype:
+            raise ValueError("X and Y must match in shape and dtype")
+        X2 = X[:, None] if X.ndim == 1 else X
+        Y2 = Y[:, None] if Y.ndim == 1 else Y
+        rc = self._lib.rk_axpby_cols(
+            _dt(X2), X2.shape[0], X2.shape[1], _ptr(X2), X2.stride(0), _ptr(a), _ptr(Y2),
+            Y2.stride(0), _ptr(b), _stream(dev),
+        )
+        _lib.check(rc, "rk_axpby_cols")
+        return Y
+
     def small_solve(self, A, B):
         """float64 device solve A X = B, A (k x k), B (k x nrhs), k, nrhs <= 16."""
         dev = _req(A, B)

@@ -59,6 +59,12 @@ class OracleBackend:
     def pcg_update_p(self, P, Z, beta):
         P.copy_(Z + P @ beta.to(P.dtype))
 
+    def axpby_cols(self, X, a, Y, b=None):
+        av = 1.0 if a is None else a.to(X.dtype)
+        new = X * av if b is None else X * av + Y * b.to(X.dtype)
+        Y.copy_(new)
+        return Y
+
     def small_solve(self, A, B):
         return torch.linalg.solve(A, B)
 
