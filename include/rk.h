@@ -120,10 +120,13 @@ int rk_matmat_skinny_t(int dtype, const void* A, int64_t m, int64_t n, int64_t l
 /* C (m x n) = alpha * op(A) (m x kd) @ op(B) (kd x n) + beta * C, row-major, MFMA
  * (v_mfma_f32_32x32x2_f32 / v_mfma_f64_16x16x4_f64).  transX != 0 means the operand is
  * stored transposed (A stored kd x m).  Serves Y = A @ Omega (rlaopt/sketches/sketch.py:
- * 86-95), U = Y @ M and dense `A @ X` with many columns. */
+ * 86-95), U = Y @ M and dense `A @ X` with many columns.  When the output has too few
+ * 128 x 128 tiles to fill the chip the reduction dimension is split (fixed-order reduce,
+ * scratch from rk_gemm_ws_bytes; 0 when no split is planned). */
+size_t rk_gemm_ws_bytes(int dtype, int64_t m, int64_t n, int64_t kd);
 int rk_gemm(int dtype, int transA, int transB, int64_t m, int64_t n, int64_t kd,
             double alpha, const void* A, int64_t lda, const void* B, int64_t ldb,
-            double beta, void* C, int64_t ldc, void* stream);
+            double beta, void* C, int64_t ldc, void* ws, size_t ws_bytes, void* stream);
 
 /* C (m x n, FLOAT64) = A^T @ B with A (rows x m), B (rows x n) of `dtype`, accumulated in
  * float64 on the f64 matrix cores and split over `rows` (deterministic two-stage

@@ -246,9 +246,31 @@ static void gram_plan(int64_t rows, int64_t m, int64_t n, int64_t* S, int64_t* k
 
 using namespace rk;
 
+// split the reduction dimension when the output has too few tiles to fill 256 CUs
+static void gemm_plan(int64_t m, int64_t n, int64_t kd, int64_t* S, int64_t* kslice) {
+    const int64_t tiles = ceil_div(m, BM) * ceil_div(n, BN);
+    int64_t s = 1;
+    if (tiles < 256) {
+        s = ceil_div(512, tiles);
+        const int64_t max_s = ceil_div(kd, 16 * BK);
+        if (s > max_s) s = max_s;
+        if (s < 1) s = 1;
+    }
+    *kslice = round_up(ceil_div(kd, s), BK);
+    *S = ceil_div(kd, *kslice);
+}
+
+extern "C" size_t rk_gemm_ws_bytes(int dtype, int64_t m, int64_t n, int64_t kd) {
+    if (m <= 0 || n <= 0 || kd <= 0) return 0;
+    int64_t S, ks;
+    gemm_plan(m, n, kd, &S, &ks);
+    return S > 1 ? (size_t)S * m * n * (dtype == RK_F32 ? 4 : 8) : 0;
+}
+
 extern "C" int rk_gemm(int dtype, int transA, int transB, int64_t m, int64_t n, int64_t kd,
                        double alpha, const void* A, int64_t lda, const void* B, int64_t ldb,
-                       double beta, void* C, int64_t ldc, void* stream) {
+                       double beta, void* C, int64_t ldc, void* ws, size_t ws_bytes,
+                       void* stream) {
     clear_error();
     RK_REQUIRE(dtype == RK_F32 || dtype == RK_F64, "rk_gemm: bad dtype %d", dtype);
     RK_REQUIRE(A && B && C, "rk_gemm: null pointer");
@@ -256,13 +278,38 @@ extern "C" int rk_gemm(int dtype, int transA, int transB, int64_t m, int64_t n, 
     RK_REQUIRE(lda >= (transA ? m : kd) && ldb >= (transB ? kd : n) && ldc >= n,
                "rk_gemm: leading dimension too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == RK_F32)
-        return gemm_dispatch<float, float>(transA, transB, m, n, kd, alpha, (const float*)A, lda,
-                                           (const float*)B, ldb, beta, (float*)C, ldc, nullptr, 1,
-                                           kd, st);
-    return gemm_dispatch<double, double>(transA, transB, m, n, kd, alpha, (const double*)A, lda,
-                                         (const double*)B, ldb, beta, (double*)C, ldc, nullptr, 1, kd,
-                                         st);
+    int64_t S, ks;
+    gemm_plan(m, n, kd, &S, &ks);
+    if (S > 1) {
+        const size_t need = (size_t)S * m * n * (dtype == RK_F32 ? 4 : 8);
+        if (ws == nullptr || ws_bytes < need) {
+            set_error("rk_gemm: workspace %zu B < required %zu B", ws_bytes, need);
+            return RK_ERR_WORKSPACE;
+        }
+    }
+    int rc;
+    if (dtype == RK_F32) {
+        float* part = S > 1 ? static_cast<float*>(ws) : nullptr;
+        rc = gemm_dispatch<float, float>(transA, transB, m, n, kd, alpha, (const float*)A, lda,
+                                         (const float*)B, ldb, beta, (float*)C, ldc, part, S, ks, st);
+        if (rc == RK_OK && S > 1) {
+            hipLaunchKernelGGL((splitk_reduce<float, float>), dim3((unsigned)ceil_div(m * n, 256)),
+                               dim3(256), 0, st, part, (int)S, m, n, (float)alpha, (float)beta,
+                               (float*)C, ldc);
+            rc = launch_status("rk_gemm(reduce)");
+        }
+    } else {
+        double* part = S > 1 ? static_cast<double*>(ws) : nullptr;
+        rc = gemm_dispatch<double, double>(transA, transB, m, n, kd, alpha, (const double*)A, lda,
+                                           (const double*)B, ldb, beta, (double*)C, ldc, part, S, ks,
+                                           st);
+        if (rc == RK_OK && S > 1) {
+            hipLaunchKernelGGL((splitk_reduce<double, double>), dim3((unsigned)ceil_div(m * n, 256)),
+                               dim3(256), 0, st, part, (int)S, m, n, alpha, beta, (double*)C, ldc);
+            rc = launch_status("rk_gemm(reduce)");
+        }
+    }
+    return rc;
 }
 
 extern "C" size_t rk_gram_tn_ws_bytes(int64_t rows, int64_t m, int64_t n) {

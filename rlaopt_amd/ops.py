@@ -224,9 +224,10 @@ class HipBackend:
         else:
             if beta != 0.0:
                 out.copy_(C2)
+            ws, wsn = self._workspace(dev, self._lib.rk_gemm_ws_bytes(_dt(A), m, k, n))
             rc = self._lib.rk_gemm(
                 _dt(A), 0, 0, m, k, n, float(alpha), _ptr(A), lda, _ptr(V2), ldv, float(beta),
-                _ptr(out), k, _stream(dev),
+                _ptr(out), k, _ptr(ws), wsn, _stream(dev),
             )
             _lib.check(rc, "rk_gemm")
             if diag_shift != 0.0:
@@ -270,9 +271,10 @@ class HipBackend:
             else:
                 if beta != 0.0:
                     out.copy_(C2)
+                ws, wsn = self._workspace(dev, self._lib.rk_gemm_ws_bytes(_dt(A), n, k, m))
                 rc = self._lib.rk_gemm(
                     _dt(A), 1, 0, n, k, m, float(alpha), _ptr(A), lda, _ptr(V2), ldv,
-                    float(beta), _ptr(out), k, _stream(dev),
+                    float(beta), _ptr(out), k, _ptr(ws), wsn, _stream(dev),
                 )
                 _lib.check(rc, "rk_gemm")
         return out[:, 0] if squeeze else out
@@ -289,9 +291,10 @@ class HipBackend:
         if kd != kb:
             raise ValueError("inner dimensions differ")
         out = torch.empty((m, n), dtype=A.dtype, device=dev)
+        ws, wsn = self._workspace(dev, self._lib.rk_gemm_ws_bytes(_dt(A), m, n, kd))
         rc = self._lib.rk_gemm(
             _dt(A), int(transA), int(transB), m, n, kd, float(alpha), _ptr(A), lda, _ptr(B), ldb,
-            0.0, _ptr(out), n, _stream(dev),
+            0.0, _ptr(out), n, _ptr(ws), wsn, _stream(dev),
         )
         _lib.check(rc, "rk_gemm")
         return out

@@ -14,3 +14,9 @@ class Identity(Preconditioner):
 
     def _inverse_matmul_2d(self, x):
         return x
+
+    def _right_solve(self, x):
+        return x
+
+    def _right_solve_t(self, x):
+        return x

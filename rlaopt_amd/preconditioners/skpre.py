@@ -53,3 +53,12 @@ class SkPre(Preconditioner):
 
     _inverse_matmul_1d = _solve
     _inverse_matmul_2d = _solve
+
+    # split factors for RIGHT preconditioning (LSQR on A R^-1 with R = L^T, G = L L^T):
+    def _right_solve(self, x):
+        """R^-1 x = L^-T x."""
+        return get_backend().rmatmat(self._Linv, x)
+
+    def _right_solve_t(self, x):
+        """R^-T x = L^-1 x."""
+        return get_backend().matmat(self._Linv, x)

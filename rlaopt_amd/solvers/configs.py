@@ -10,7 +10,7 @@ from ..preconditioners import IdentityConfig, PreconditionerConfig, _is_precond_
 from ..utils import _is_bool, _is_nonneg_float, _is_pos_float, _is_pos_int, _is_torch_device
 
 __all__ = [
-    "SAPAccelConfig", "SolverConfig", "PCGConfig", "SAPConfig", "_is_solver_config",
+    "SAPAccelConfig", "SolverConfig", "PCGConfig", "SAPConfig", "LSQRConfig", "_is_solver_config",
     "_get_solver_name",
 ]
 
@@ -90,6 +90,22 @@ class SAPConfig(SolverConfig):
         _is_pos_int(self.power_iters, "power_iters")
 
 
+@dataclass(kw_only=True, frozen=False)
+class LSQRConfig(SolverConfig):
+    """LSQR for ``LeastSquares`` models (no reference counterpart: SURVEY 8a row a14; follows the
+    SolverConfig pattern of configs.py:53-107).  ``precond_config``: IdentityConfig or
+    SkPreConfig (right preconditioning with the sketch-and-precondition factor)."""
+
+    device: torch.device
+    max_iters: int = 1000
+    atol: float = 0.0
+    rtol: float = 1e-5
+    precond_config: PreconditionerConfig = field(default_factory=IdentityConfig)
+
+    def __post_init__(self):
+        _check_common(self)
+
+
 def _is_solver_config(param: Any, param_name: str):
     if not isinstance(param, SolverConfig):
         raise TypeError(
@@ -98,4 +114,4 @@ def _is_solver_config(param: Any, param_name: str):
 
 
 def _get_solver_name(solver_config: SolverConfig) -> str:
-    return {PCGConfig: "pcg", SAPConfig: "sap"}.get(type(solver_config))
+    return {PCGConfig: "pcg", SAPConfig: "sap", LSQRConfig: "lsqr"}.get(type(solver_config))

@@ -321,3 +321,51 @@ def test_api_validation_errors(dev):
     sysm = LinSys(torch.eye(3, dtype=torch.float64, device=dev), torch.zeros(3, dtype=torch.float64, device=dev))
     with pytest.raises(ValueError):  # 1-D W_init is refused (the reference silently broadcasts)
         sysm.solve(PCGConfig(device=dev), torch.zeros(3, dtype=torch.float64, device=dev))
+
+
+@pytest.mark.parametrize("reg", [0.0, 0.05])
+@pytest.mark.parametrize("precond", ["identity", "skpre"])
+def test_least_squares_lsqr_matches_oracle(dev, prec, reg, precond):
+    """LeastSquares + LSQR (+ SkPre right preconditioning) against oracle/lsqr.py (itself
+    checked against scipy): same iterates early on, same solution at convergence."""
+    from oracle import lsqr as olsqr
+    from rlaopt_amd.models import LeastSquares
+    from rlaopt_amd.solvers import LSQRConfig
+
+    dt = DTYPES[prec]
+    f64 = dt == torch.float64
+    g = torch.Generator().manual_seed(2)
+    m, d, k, s = 900, 24, 2, 96
+    A = (torch.randn(m, d, dtype=torch.float64, generator=g) * torch.logspace(0, -2, d, dtype=torch.float64)).to(dt)
+    B = torch.randn(m, k, dtype=torch.float64, generator=g).to(dt)
+    Om = (torch.randn(s, m, dtype=torch.float64, generator=g) / s**0.5).to(dt)
+    rho = max(reg, 1e-12)
+    Rinv = None
+    if precond == "skpre":
+        Y = Om.double() @ A.double()
+        L = torch.linalg.cholesky(Y.T @ Y + rho * torch.eye(d, dtype=torch.float64))
+        Rinv = torch.linalg.inv(L.T)
+    pcfg = IdentityConfig() if precond == "identity" else SkPreConfig(sketch_size=s, rho=rho, sketch="gauss")
+    iters = 6
+    x_ref, _ = olsqr.lsqr(A.double(), B.double(), reg=reg, Rinv=Rinv, iters=iters)
+    system = LeastSquares(A.to(dev), B.to(dev), reg=reg)
+    cfg = LSQRConfig(device=dev, max_iters=iters, atol=0.0, rtol=1e-14, precond_config=pcfg)
+    with sketches.inject(Om):
+        W, log = system.solve(cfg, torch.zeros(d, k, dtype=dt, device=dev), callback_freq=3)
+    assert sorted(log) == [0, 3, 6]
+    assert set(log[3]["metrics"]["internal_metrics"]) == {"abs_res", "rel_res", "misfit"}
+    err = float((W.cpu().double() - x_ref).norm() / x_ref.norm())
+    assert err < (1e-9 if f64 else 2e-4), err
+    # run to convergence: ridge / least-squares solution
+    want = torch.linalg.solve(A.double().T @ A.double() + reg * torch.eye(d, dtype=torch.float64),
+                              A.double().T @ B.double())
+    rtol = 1e-10 if f64 else 1e-4
+    cfg = LSQRConfig(device=dev, max_iters=400, atol=0.0, rtol=rtol, precond_config=pcfg)
+    system = LeastSquares(A.to(dev), B.to(dev), reg=reg)
+    with sketches.inject(Om):
+        W, log = system.solve(cfg, torch.zeros(d, k, dtype=dt, device=dev), callback_freq=5)
+    assert float(log[max(log)]["metrics"]["internal_metrics"]["rel_res"].max()) <= rtol
+    if precond == "skpre":
+        assert max(log) <= 40  # sketch-and-precondition: condition number O(1)
+    err = float((W.cpu().double() - want).norm() / want.norm())
+    assert err < (1e-6 if f64 else 5e-2), err
