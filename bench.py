@@ -16,9 +16,11 @@ Setup (materialising the kernel shard, Nystrom assembly) is outside the timed re
 reported separately; inputs are resident in HBM when the timed region starts.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-``roofline`` for the dominant kernel (the HBM-streaming shard product ``rk_matmat_skinny``;
-algorithmic bytes per launch = (n_loc n + n k + n_loc k) * 4, duration from HIP events on the
-launch stream inside the timed region) and ``cpu_baseline`` (the oracle's C restatement of the
+``roofline`` for the dominant kernel - the HBM-streaming kernel product: for symmetric data
+(A1 is A2, the KRR case) ``rk_symm_matmat`` over the strip-packed upper triangle, algorithmic
+bytes = packed triangle + V + Y; otherwise ``rk_matmat_skinny`` over the row-major shard,
+(n_loc n + n k + n_loc k) * 4 bytes - duration from HIP events on the launch stream inside the
+timed region (the row-major kernel is additionally timed on a 1/8 shard: ``rowmajor_shard_product``) and ``cpu_baseline`` (the oracle's C restatement of the
 matrix-free kernel product timed on the host cores over a bounded row sample, rank 0, N = 1).
 """
 
@@ -83,7 +85,7 @@ def cpu_baseline(X, n, budget_s=12.0):
     }
 
 
-def committed_traffic(world, n):
+def committed_traffic(world, n, mode):
     """HBM bytes per shard-product launch from the committed PMC summary (profiles/*_traffic.json,
     written by tools/summarize_profile.py from separate rocprofv3 --pmc passes) when one exists
     for this exact workload; None otherwise."""
@@ -95,7 +97,7 @@ def committed_traffic(world, n):
             rec = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if rec.get("n_gpus") == world and f"n={n} " in rec.get("workload", ""):
+        if rec.get("n_gpus") == world and f"n={n} " in rec.get("workload", "") and rec.get("storage") == mode:
             best = rec
     return None if best is None else best["hbm_bytes_per_launch"]
 
@@ -186,12 +188,36 @@ def main():
         elapsed = float(tmax)
     rel_now = float(system._compute_internal_metrics(solver.W)["rel_res"][0])
 
+    mode = A.storage_mode
     mv = timing.get("kernel_shard_product", {"avg_ms": float("nan"), "bytes_per_launch": 0, "launches": 0})
     achieved = mv["bytes_per_launch"] / (mv["avg_ms"] * 1e-3) / 1e9 if mv["launches"] else float("nan")
     if world > 1:  # roofline is per GPU: report the slowest rank's kernel
         amin = torch.tensor([achieved], dtype=torch.float64, device=dev)
         td.all_reduce(amin, op=td.ReduceOp.MIN)
         achieved = float(amin)
+
+    # ---- the row-major streaming kernel on a 1/8 row shard (SURVEY 8d formula), for reference ------
+    rowmajor = None
+    if rank == 0:
+        rows8 = n // 8
+        Ksh = be.kernel_materialize("rbf", Xd[:rows8], Xd, 1.0)
+        vv = torch.randn(n, 1, device=dev)
+        be.matmat(Ksh, vv)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            be.matmat(Ksh, vv, diag_shift=reg, row0=0)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        nbytes = (rows8 * n + n + rows8) * 4
+        rowmajor = {"kernel": "rk_matmat_skinny (skinny_nn_kernel<float,1,8>)", "shard": f"{rows8} x {n} fp32 (the p = 8 shard)",
+                    "avg_launch_ms": ms, "achieved_GBps": nbytes / (ms * 1e-3) / 1e9,
+                    "frac_of_8000": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        del Ksh, vv
+    if world > 1:
+        td.barrier()
 
     # ---- full solve to the reference tolerance (reported, not the headline) ---------------------
     solve = {}
@@ -234,18 +260,25 @@ def main():
                 "parallelism": f"row-shard x{world}",
             },
             "roofline": {
-                "kernel": "rk_matmat_skinny (skinny_nn_kernel<float,1,8>)",
+                "kernel": ("rk_symm_matmat (symm_strip_kernel<float,1>): strip-packed upper triangle, every "
+                           "stored entry used for y[i] and y[j]; algorithmic bytes = packed triangle + V + Y"
+                           if mode == "sympack" else
+                           "rk_matmat_skinny (skinny_nn_kernel<float,1,8>): row-major shard; algorithmic "
+                           "bytes = (n_loc n + n k + n_loc k) * 4"),
+                "storage": mode,
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": committed_traffic(world, n),
+                "traffic": committed_traffic(world, n, mode),
                 "bytes_per_launch": mv["bytes_per_launch"],
                 "avg_launch_ms": mv["avg_ms"],
                 "launches": mv["launches"],
             },
             "matvec_GBps_aggregate": achieved * world,
+            "matvec_dense_equivalent_GBps_aggregate": (n * n * 4.0 / (mv["avg_ms"] * 1e-3) / 1e9) if mv["launches"] else None,
+            "rowmajor_shard_product": rowmajor,
             "setup_materialize_s": round(t_mat, 3),
             "setup_nystrom_s": round(t_pre, 3),
             "rel_res_after_timed_steps": rel_now,

@@ -83,6 +83,26 @@ int rk_kernel_matmat(int dtype, int kind,
                      void* Y, int64_t ldy, int accumulate,
                      void* ws, size_t ws_bytes, void* stream);
 
+/* Symmetric operators K(X, X), "sympack" storage: columns are cut into strips of
+ * W = 256 (f32) / 128 (f64) columns; strip s keeps rows 0 .. min(n, (s+1) W) - 1 of its W
+ * columns (the part on and above its diagonal block), row-major with leading dimension W,
+ * strips concatenated; a rank keeps the strips s = strip_first + t * strip_stride (cyclic over
+ * ranks).  Half the bytes of the row-major block; rk_symm_matmat reads every stored entry once
+ * and uses it for y[i] += K[i][j] v[j] AND y[j] += K[i][j] v[i].  The result of rk_symm_matmat
+ * is this rank's PARTIAL sum over its strips (complete when strip_stride == 1); partials of
+ * different ranks add up to K V (all-reduce).  1 <= k <= 4 per call.  No reference
+ * counterpart: the reference never exploits A1 is A2 (rlaopt/kernels/base.py:23-128). */
+size_t rk_sympack_elems(int dtype, int64_t n, int64_t strip_first, int64_t strip_stride);
+int rk_kernel_materialize_sympack(int dtype, int kind, const void* X, int64_t n, int64_t ldx,
+                                  int64_t d, double ell_scalar, const void* ell_vec, double scale,
+                                  int64_t strip_first, int64_t strip_stride, void* Kp, void* stream);
+size_t rk_symm_matmat_ws_bytes(int dtype, int64_t n, int64_t k, int64_t strip_first,
+                               int64_t strip_stride);
+/* Y (n x k) = alpha * (partial) K V + diag_shift * V */
+int rk_symm_matmat(int dtype, const void* Kp, int64_t n, int64_t strip_first, int64_t strip_stride,
+                   const void* V, int64_t k, int64_t ldv, double alpha, double diag_shift,
+                   void* Y, int64_t ldy, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * HBM-streaming skinny products  [a3 cached shard product, a6 dense tensor operator,
  * a9 Nystrom apply, a11 block dots]

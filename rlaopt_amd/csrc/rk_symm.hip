@@ -1,0 +1,405 @@
+// Symmetric kernel matrices K(X, X): strip-packed upper-triangular storage and the product
+// that reads every stored entry once and uses it twice.
+//
+// Layout ("sympack").  Columns are cut into strips of W = 64 x 16 B / sizeof(T) columns
+// (256 fp32 / 128 fp64).  Strip s stores rows 0 .. min(n, (s+1) W) - 1 of its W columns - the
+// part on and above its diagonal block, the diagonal block in full - row-major with leading
+// dimension W (every stored row is exactly one 1 KiB wave load; columns past n are zero).
+// A rank stores the strips s = first, first + stride, ... (cyclic distribution: balanced to
+// within one strip); total elements ~ n^2 / (2 stride): HALF of the row-major shard.
+//
+// Product y = K v for symmetric K.  A wave walks down a strip: for a stored row i of strip s
+//     y[i]       += sum_j K[i][j] v[j]      (j in the strip)   - a wave reduction per row
+//     y[j]       += K[i][j] v[i]            (i above the diagonal block only) - per-lane sums
+// The per-row wave reduction is 4 v_add_f32_dpp + 2 row_bcast steps (no LDS traffic), the
+// column sums stay in registers for the whole item.  Row results go to a (strip, row) table,
+// column results to an (item, column) table; a finishing kernel adds them in a fixed order
+// (bitwise reproducible, no atomics) and applies alpha and the "+ reg v" term.
+// HBM traffic: the packed triangle once (+ ~1 % of partial tables) instead of the full square.
+#include "rk_common.h"
+#include "rk_kerneltile.h"
+
+namespace rk {
+
+struct SymLayout {
+    int64_t n;
+    int W;
+    int64_t first, stride;
+
+    __host__ __device__ int64_t strips_total() const { return (n + W - 1) / W; }
+    __host__ __device__ int64_t strips_local() const {
+        const int64_t S = strips_total();
+        return first < S ? (S - first + stride - 1) / stride : 0;
+    }
+    __host__ __device__ int64_t strip(int64_t t) const { return first + t * stride; }
+    __host__ __device__ int64_t rows(int64_t t) const {
+        const int64_t r = (strip(t) + 1) * W;
+        return r < n ? r : n;
+    }
+    // stored rows before local strip t (only the globally last strip is clipped, and it can
+    // only be the last local one, so every earlier strip s' has (s'+1) W rows)
+    __host__ __device__ int64_t row_offset(int64_t t) const {
+        return (int64_t)W * (t * (first + 1) + stride * (t * (t - 1) / 2));
+    }
+    __host__ __device__ int64_t total_rows() const {
+        const int64_t T = strips_local();
+        return T ? row_offset(T - 1) + rows(T - 1) : 0;
+    }
+};
+
+template <typename T>
+constexpr int strip_width() { return kWave * Vec16<T>::N; }
+
+constexpr int ITEM_ROWS = 1024;  // rows of a strip handled by one workgroup (4 waves x 256)
+
+// ------------------------------------------------------------------------------------------
+// materialise the packed triangle
+// ------------------------------------------------------------------------------------------
+template <typename T, bool L1>
+__global__ void __launch_bounds__(256)
+sympack_materialize_kernel(int kind, const T* __restrict__ X, int64_t ldx, int64_t d, T w,
+                           const T* __restrict__ ell_vec, T scale, SymLayout L,
+                           T* __restrict__ Kp) {
+    constexpr int W = strip_width<T>();
+    constexpr int CT = W / TN;  // column tiles per strip
+    __shared__ T xs[DC][LDP];
+    __shared__ T ys[DC][LDP];
+    const int64_t t = blockIdx.y;
+    const int64_t nrows = L.rows(t);
+    const int64_t i0 = ((int64_t)blockIdx.x / CT) * TM;
+    if (i0 >= nrows) return;  // uniform: before any barrier
+    const int jt = (int)(blockIdx.x % CT);
+    const int64_t j0 = L.strip(t) * W + (int64_t)jt * TN;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    T acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[r][q] = T(0);
+    for (int64_t c0 = 0; c0 < d; c0 += DC) {
+        __syncthreads();
+        stage_panel<T>(xs, X, L.n, ldx, nullptr, i0, c0, d, ell_vec);
+        stage_panel<T>(ys, X, L.n, ldx, nullptr, j0, c0, d, ell_vec);
+        __syncthreads();
+        tile_accumulate<T, L1>(xs, ys, ty, tx, acc);
+    }
+    T* base = Kp + L.row_offset(t) * W;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = i0 + ty * 4 + r;
+        if (i >= nrows) continue;
+        T o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t j = j0 + tx * 4 + q;
+            o[q] = (j < L.n) ? scale * kernel_value<T>(kind, acc[r][q], w) : T(0);
+        }
+        T* dst = base + i * W + jt * TN + tx * 4;
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+            *reinterpret_cast<double2*>(dst) = make_double2(o[0], o[1]);
+            *reinterpret_cast<double2*>(dst + 2) = make_double2(o[2], o[3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// wave total in lane 63 without LDS: 4 DPP adds inside each 16-lane row, then row broadcasts
+// ------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_fetch(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_fetch(double v) {
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, ROW_MASK, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <typename T>
+__device__ __forceinline__ T wave_total_lane63(T v) {
+    v += dpp_fetch<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v += dpp_fetch<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v += dpp_fetch<0x141, 0xF>(v);  // row_half_mirror
+    v += dpp_fetch<0x140, 0xF>(v);  // row_mirror: every lane holds its 16-lane row sum
+    v += dpp_fetch<0x142, 0xA>(v);  // row_bcast15 -> rows 1 and 3
+    v += dpp_fetch<0x143, 0xC>(v);  // row_bcast31 -> rows 2 and 3: lane 63 holds the total
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// the strip product
+// ------------------------------------------------------------------------------------------
+template <typename T, int K>
+__global__ void __launch_bounds__(256)
+symm_strip_kernel(const T* __restrict__ Kp, SymLayout L, const T* __restrict__ V, int64_t ldv,
+                  T* __restrict__ Prow, T* __restrict__ Pcol, int64_t max_items) {
+    using V16 = typename Vec16<T>::type;
+    constexpr int VW = Vec16<T>::N;
+    constexpr int W = strip_width<T>();
+    constexpr int RB = 8;                     // rows per batch (loads in flight per stage)
+    constexpr int WAVE_ROWS = ITEM_ROWS / 4;  // 256
+    __shared__ T rowbuf[4][WAVE_ROWS][K];
+    __shared__ T colbuf[4][W][K];
+
+    const int64_t t = blockIdx.y;
+    const int64_t nrows = L.rows(t);
+    const int64_t item_lo = (int64_t)blockIdx.x * ITEM_ROWS;
+    if (item_lo >= nrows) return;  // uniform over the workgroup, before any barrier
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t s = L.strip(t);
+    const int64_t diag_lo = s * W;  // rows >= diag_lo belong to the (fully stored) diagonal block
+    const T* base = Kp + L.row_offset(t) * W;
+    const int64_t r_lo = item_lo + (int64_t)wave * WAVE_ROWS;
+    int64_t r_hi = r_lo + WAVE_ROWS;
+    if (r_hi > nrows) r_hi = nrows;
+
+    // this lane's VW columns of the strip and their right-hand-side entries
+    T vj[VW][K];
+#pragma unroll
+    for (int q = 0; q < VW; ++q) {
+        const int64_t j = diag_lo + lane * VW + q;
+#pragma unroll
+        for (int c = 0; c < K; ++c) vj[q][c] = (j < L.n) ? V[j * ldv + c] : T(0);
+    }
+    T col[VW][K];
+#pragma unroll
+    for (int q = 0; q < VW; ++q)
+#pragma unroll
+        for (int c = 0; c < K; ++c) col[q][c] = T(0);
+
+    V16 cur[RB], nxt[RB];
+    T vcur[RB][K], vnxt[RB][K];
+    auto fetch = [&](V16 a[RB], T vi[RB][K], int64_t i0) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            int64_t i = i0 + r;
+            if (i > nrows - 1) i = nrows - 1;  // clamp; contribution masked below
+            a[r] = *reinterpret_cast<const V16*>(base + i * W + lane * VW);
+#pragma unroll
+            for (int c = 0; c < K; ++c) vi[r][c] = V[i * ldv + c];  // wave-uniform address
+        }
+    };
+    if (r_lo < r_hi) fetch(cur, vcur, r_lo);
+    for (int64_t i0 = r_lo; i0 < r_hi; i0 += RB) {
+        if (i0 + RB < r_hi) fetch(nxt, vnxt, i0 + RB);
+        const bool above = i0 < diag_lo;  // batch-uniform: diag_lo and i0 are multiples of 8
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const bool live = i0 + r < r_hi;
+            const T* ae = reinterpret_cast<const T*>(&cur[r]);
+            T dot[K];
+#pragma unroll
+            for (int c = 0; c < K; ++c) dot[c] = T(0);
+#pragma unroll
+            for (int q = 0; q < VW; ++q)
+#pragma unroll
+                for (int c = 0; c < K; ++c) dot[c] += ae[q] * vj[q][c];
+            if (above && live) {
+#pragma unroll
+                for (int q = 0; q < VW; ++q)
+#pragma unroll
+                    for (int c = 0; c < K; ++c) col[q][c] += ae[q] * vcur[r][c];
+            }
+#pragma unroll
+            for (int c = 0; c < K; ++c) {
+                const T tot = wave_total_lane63(dot[c]);
+                if (lane == 63 && live) rowbuf[wave][i0 - r_lo + r][c] = tot;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            cur[r] = nxt[r];
+#pragma unroll
+            for (int c = 0; c < K; ++c) vcur[r][c] = vnxt[r][c];
+        }
+    }
+    // row sums of this wave's rows -> Prow, coalesced
+#pragma unroll
+    for (int q = 0; q < VW; ++q)
+#pragma unroll
+        for (int c = 0; c < K; ++c) colbuf[wave][lane * VW + q][c] = col[q][c];
+    __syncthreads();  // rowbuf (written by lane 63) and colbuf are complete
+    const int64_t prow0 = L.row_offset(t) + r_lo;
+    for (int e = lane; e < (int)(r_hi > r_lo ? (r_hi - r_lo) : 0) * K; e += 64)
+        Prow[prow0 * K + e] = rowbuf[wave][e / K][e % K];
+    // column sums of the 4 waves -> Pcol[item]
+    T* pc = Pcol + ((t * max_items + blockIdx.x) * W) * K;
+    for (int e = threadIdx.x; e < W * K; e += 256) {
+        const int j = e / K, c = e - j * K;
+        pc[e] = ((colbuf[0][j][c] + colbuf[1][j][c]) + colbuf[2][j][c]) + colbuf[3][j][c];
+    }
+}
+
+// Y[i][c] = alpha * (row parts of every local strip that stores row i
+//                    + column parts of the local strip that owns column i) + shift * V[i][c]
+template <typename T>
+__global__ void __launch_bounds__(256)
+symm_finish_kernel(SymLayout L, int K, const T* __restrict__ Prow, const T* __restrict__ Pcol,
+                   int64_t max_items, T alpha, T shift, const T* __restrict__ V, int64_t ldv,
+                   T* __restrict__ Y, int64_t ldy) {
+    const int W = L.W;
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= L.n * K) return;
+    const int64_t i = e / K;
+    const int c = (int)(e - i * K);
+    const int64_t blk = i / W;
+    const int64_t T_loc = L.strips_local();
+    T sum = T(0);
+    int64_t t0 = blk <= L.first ? 0 : (blk - L.first + L.stride - 1) / L.stride;
+    for (int64_t t = t0; t < T_loc; ++t) sum += Prow[(L.row_offset(t) + i) * K + c];
+    if (blk >= L.first && (blk - L.first) % L.stride == 0) {
+        const int64_t t = (blk - L.first) / L.stride;
+        const int64_t items = (L.rows(t) + ITEM_ROWS - 1) / ITEM_ROWS;
+        const int64_t jloc = i - blk * W;
+        for (int64_t it = 0; it < items; ++it)
+            sum += Pcol[((t * max_items + it) * W + jloc) * K + c];
+    }
+    T y = alpha * sum;
+    if (shift != T(0)) y += shift * V[i * ldv + c];
+    Y[i * ldy + c] = y;
+}
+
+template <typename T>
+static SymLayout make_layout(int64_t n, int64_t first, int64_t stride) {
+    SymLayout L;
+    L.n = n;
+    L.W = strip_width<T>();
+    L.first = first;
+    L.stride = stride;
+    return L;
+}
+
+template <typename T>
+static int sympack_materialize_impl(int kind, const T* X, int64_t n, int64_t ldx, int64_t d,
+                                    double ell, const T* ell_vec, double scale, int64_t first,
+                                    int64_t stride, T* Kp, hipStream_t st) {
+    const SymLayout L = make_layout<T>(n, first, stride);
+    const int64_t T_loc = L.strips_local();
+    if (T_loc == 0) return RK_OK;
+    constexpr int CT = strip_width<T>() / TN;
+    const int64_t max_rows = L.rows(T_loc - 1);
+    dim3 grid((unsigned)(ceil_div(max_rows, TM) * CT), (unsigned)T_loc);
+    const T w = ell_vec ? T(1) : T(1.0 / ell);
+    if (kind == RK_LAPLACE)
+        hipLaunchKernelGGL((sympack_materialize_kernel<T, true>), grid, dim3(256), 0, st, kind, X,
+                           ldx, d, w, ell_vec, (T)scale, L, Kp);
+    else
+        hipLaunchKernelGGL((sympack_materialize_kernel<T, false>), grid, dim3(256), 0, st, kind, X,
+                           ldx, d, w, ell_vec, (T)scale, L, Kp);
+    return launch_status("rk_kernel_materialize_sympack");
+}
+
+template <typename T>
+static size_t symm_ws_bytes(int64_t n, int64_t k, int64_t first, int64_t stride) {
+    const SymLayout L = make_layout<T>(n, first, stride);
+    const int64_t max_items = ceil_div(n, ITEM_ROWS);
+    const size_t prow = (size_t)L.total_rows() * k;
+    const size_t pcol = (size_t)L.strips_local() * max_items * L.W * k;
+    return (prow + pcol) * sizeof(T);
+}
+
+template <typename T>
+static int symm_matmat_impl(const T* Kp, int64_t n, int64_t first, int64_t stride, const T* V,
+                            int64_t k, int64_t ldv, double alpha, double shift, T* Y, int64_t ldy,
+                            void* ws, size_t ws_bytes, hipStream_t st) {
+    const SymLayout L = make_layout<T>(n, first, stride);
+    const int64_t T_loc = L.strips_local();
+    const int64_t max_items = ceil_div(n, ITEM_ROWS);
+    const size_t need = symm_ws_bytes<T>(n, k, first, stride);
+    if (need > 0 && (ws == nullptr || ws_bytes < need)) {
+        set_error("rk_symm_matmat: workspace %zu B < required %zu B", ws_bytes, need);
+        return RK_ERR_WORKSPACE;
+    }
+    T* Prow = static_cast<T*>(ws);
+    T* Pcol = Prow + (size_t)L.total_rows() * k;
+    if (T_loc > 0) {
+        dim3 grid((unsigned)ceil_div(L.rows(T_loc - 1), ITEM_ROWS), (unsigned)T_loc);
+#define RK_SYMM(KK)                                                                             \
+    hipLaunchKernelGGL((symm_strip_kernel<T, KK>), grid, dim3(256), 0, st, Kp, L, V, ldv, Prow,  \
+                       Pcol, max_items)
+        switch (k) {
+            case 1: RK_SYMM(1); break;
+            case 2: RK_SYMM(2); break;
+            case 3: RK_SYMM(3); break;
+            default: RK_SYMM(4); break;
+        }
+#undef RK_SYMM
+        int rc = launch_status("rk_symm_matmat");
+        if (rc != RK_OK) return rc;
+    }
+    hipLaunchKernelGGL((symm_finish_kernel<T>), dim3((unsigned)ceil_div(n * k, 256)), dim3(256), 0,
+                       st, L, (int)k, Prow, Pcol, max_items, (T)alpha, (T)shift, V, ldv, Y, ldy);
+    return launch_status("rk_symm_matmat(finish)");
+}
+
+}  // namespace rk
+
+using namespace rk;
+
+static int check_layout(const char* fn, int dtype, int64_t n, int64_t first, int64_t stride) {
+    RK_REQUIRE(dtype == RK_F32 || dtype == RK_F64, "%s: bad dtype %d", fn, dtype);
+    RK_REQUIRE(n > 0, "%s: n must be positive", fn);
+    RK_REQUIRE(stride >= 1 && first >= 0 && first < stride, "%s: need 0 <= strip_first < strip_stride", fn);
+    return RK_OK;
+}
+
+extern "C" size_t rk_sympack_elems(int dtype, int64_t n, int64_t strip_first, int64_t strip_stride) {
+    if (n <= 0 || strip_stride < 1 || strip_first < 0 || strip_first >= strip_stride) return 0;
+    const SymLayout L = dtype == RK_F32 ? make_layout<float>(n, strip_first, strip_stride)
+                                        : make_layout<double>(n, strip_first, strip_stride);
+    return (size_t)L.total_rows() * L.W;
+}
+
+extern "C" int rk_kernel_materialize_sympack(int dtype, int kind, const void* X, int64_t n,
+                                             int64_t ldx, int64_t d, double ell_scalar,
+                                             const void* ell_vec, double scale, int64_t strip_first,
+                                             int64_t strip_stride, void* Kp, void* stream) {
+    clear_error();
+    int rc = check_layout("rk_kernel_materialize_sympack", dtype, n, strip_first, strip_stride);
+    if (rc != RK_OK) return rc;
+    RK_REQUIRE(kind >= RK_RBF && kind <= RK_MATERN52, "rk_kernel_materialize_sympack: bad kind %d", kind);
+    RK_REQUIRE(X && Kp, "rk_kernel_materialize_sympack: null pointer");
+    RK_REQUIRE(d > 0 && ldx >= d, "rk_kernel_materialize_sympack: bad feature dimension");
+    RK_REQUIRE(ell_vec != nullptr || ell_scalar > 0.0, "rk_kernel_materialize_sympack: lengthscale must be positive");
+    RK_REQUIRE(aligned16(Kp), "rk_kernel_materialize_sympack: output must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == RK_F32)
+        return sympack_materialize_impl<float>(kind, (const float*)X, n, ldx, d, ell_scalar,
+                                               (const float*)ell_vec, scale, strip_first,
+                                               strip_stride, (float*)Kp, st);
+    return sympack_materialize_impl<double>(kind, (const double*)X, n, ldx, d, ell_scalar,
+                                            (const double*)ell_vec, scale, strip_first, strip_stride,
+                                            (double*)Kp, st);
+}
+
+extern "C" size_t rk_symm_matmat_ws_bytes(int dtype, int64_t n, int64_t k, int64_t strip_first,
+                                          int64_t strip_stride) {
+    if (n <= 0 || k < 1 || k > 4 || strip_stride < 1 || strip_first < 0 || strip_first >= strip_stride)
+        return 0;
+    return dtype == RK_F32 ? symm_ws_bytes<float>(n, k, strip_first, strip_stride)
+                           : symm_ws_bytes<double>(n, k, strip_first, strip_stride);
+}
+
+extern "C" int rk_symm_matmat(int dtype, const void* Kp, int64_t n, int64_t strip_first,
+                              int64_t strip_stride, const void* V, int64_t k, int64_t ldv,
+                              double alpha, double diag_shift, void* Y, int64_t ldy, void* ws,
+                              size_t ws_bytes, void* stream) {
+    clear_error();
+    int rc = check_layout("rk_symm_matmat", dtype, n, strip_first, strip_stride);
+    if (rc != RK_OK) return rc;
+    RK_REQUIRE(Kp && V && Y, "rk_symm_matmat: null pointer");
+    RK_REQUIRE(k >= 1 && k <= 4, "rk_symm_matmat: k=%lld outside [1,4]", (long long)k);
+    RK_REQUIRE(ldv >= k && ldy >= k, "rk_symm_matmat: leading dimension too small");
+    RK_REQUIRE(aligned16(Kp), "rk_symm_matmat: packed matrix must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == RK_F32)
+        return symm_matmat_impl<float>((const float*)Kp, n, strip_first, strip_stride, (const float*)V,
+                                       k, ldv, alpha, diag_shift, (float*)Y, ldy, ws, ws_bytes, st);
+    return symm_matmat_impl<double>((const double*)Kp, n, strip_first, strip_stride, (const double*)V,
+                                    k, ldv, alpha, diag_shift, (double*)Y, ldy, ws, ws_bytes, st);
+}

@@ -13,7 +13,14 @@ matrix-free
     the block does not fit and for the row / block oracles whose index sets change per call
     (base.py:104-128, kernels/utils.py:10-56).
 
-``RK_KERNEL_MODE`` = "auto" | "materialize" | "matrix_free" overrides the choice.
+symmetric packed ("sympack", default when A1 is A2 and the triangle fits)
+    only the strips on and above the diagonal are stored (half the bytes, see
+    ``csrc/rk_symm.hip``) and ``rk_symm_matmat`` uses every stored entry for both y[i] and
+    y[j]: ~2x fewer HBM bytes per product.  Across ranks the strips are dealt cyclically and
+    the per-rank partial products are all-reduced.  Products with many columns (the Nystrom
+    sketch) go through temporary row-major panels and the matrix cores.
+
+``RK_KERNEL_MODE`` = "auto" | "sympack" | "materialize" | "matrix_free" overrides the choice.
 """
 
 from __future__ import annotations
@@ -36,8 +43,8 @@ _HBM_FRACTION = 0.85  # of the currently free device memory a materialised block
 
 def _mode_override() -> str:
     mode = os.environ.get("RK_KERNEL_MODE", "auto").lower()
-    if mode not in ("auto", "materialize", "matrix_free"):
-        raise ValueError(f"RK_KERNEL_MODE={mode!r}: expected auto|materialize|matrix_free")
+    if mode not in ("auto", "sympack", "materialize", "matrix_free"):
+        raise ValueError(f"RK_KERNEL_MODE={mode!r}: expected auto|sympack|materialize|matrix_free")
     return mode
 
 
@@ -47,6 +54,75 @@ def _fits_in_hbm(rows: int, cols: int, dtype: torch.dtype, device: torch.device)
         return True  # host stand-in backends (tests) have no HBM budget
     free, _total = torch.cuda.mem_get_info(device)
     return need <= _HBM_FRACTION * free
+
+
+def _same_points(A1: torch.Tensor, A2: torch.Tensor) -> bool:
+    return A1 is A2 or (
+        A1.device == A2.device and A1.data_ptr() == A2.data_ptr() and A1.shape == A2.shape
+        and A1.stride() == A2.stride()
+    )
+
+
+_PANEL_BYTES = 4 << 30  # temporary row-major panel for wide products in sympack mode
+_SYM_MAX_COLS = 16      # beyond this many columns a product goes through panels + MFMA
+
+
+class _SymPackBlock:
+    """Strip-packed K(X, X) (strips first, first + stride, ...) on one device."""
+
+    def __init__(self, kind: str, X: torch.Tensor, config: KernelConfig, first: int = 0, stride: int = 1):
+        self.kind, self.X, self.config = kind, X, config
+        self.n, self.first, self.stride = X.shape[0], first, stride
+        self.scale = float(getattr(config, "const_scaling", 1.0))
+        self._Kp = None
+        self._panel = None
+
+    @staticmethod
+    def fits(n: int, stride: int, dtype, device) -> bool:
+        es = torch.empty((), dtype=dtype).element_size()
+        need = n * n * es // (2 * stride) + _PANEL_BYTES
+        if device.type != "cuda":
+            return True
+        free, _total = torch.cuda.mem_get_info(device)
+        return need <= _HBM_FRACTION * free
+
+    @property
+    def Kp(self) -> torch.Tensor:
+        if self._Kp is None:
+            self._Kp = get_backend().sympack_materialize(
+                self.kind, self.X, self.config.lengthscale, scale=self.scale,
+                first=self.first, stride=self.stride,
+            )
+        return self._Kp
+
+    def partial_matmat(self, x, diag_shift=0.0):
+        """This rank's partial of K x (+ diag_shift x); complete when stride == 1."""
+        return get_backend().symm_matmat(
+            self.Kp, self.n, x, diag_shift=diag_shift, first=self.first, stride=self.stride,
+            tag="kernel_shard_product",
+        )
+
+    def rows_matmat_wide(self, x, lo: int, hi: int):
+        """Rows [lo, hi) of K x for many columns: temporary row-major panels + GEMM."""
+        be = get_backend()
+        es = x.element_size()
+        rpp = max(256, min(hi - lo, _PANEL_BYTES // (self.n * es)))
+        if self._panel is None or self._panel.shape[0] < min(rpp, hi - lo):
+            self._panel = torch.empty((min(rpp, hi - lo), self.n), dtype=x.dtype, device=x.device)
+        out = torch.empty((hi - lo, x.shape[1]), dtype=x.dtype, device=x.device)
+        for a in range(lo, hi, rpp):
+            b = min(hi, a + rpp)
+            panel = be.kernel_materialize(
+                self.kind, self.X[a:b], self.X, self.config.lengthscale, scale=self.scale,
+                out=self._panel[: b - a],
+            )
+            out[a - lo : b - lo] = be.matmat(panel, x)
+        self._panel = None  # the panel is only needed while a sketch is being built
+        return out
+
+    def release(self):
+        self._Kp = None
+        self._panel = None
 
 
 class _KernelBlock:
@@ -119,14 +195,21 @@ class _KernelLinOp(TwoSidedLinOp, ScaleMixin):
         _check_data(A1, A2, kernel_config, same_device=True)
         self._A1, self._A2, self._kernel_config, self._kind = A1, A2, kernel_config, _kernel_kind
         self._initialize_scaling(getattr(kernel_config, "const_scaling", 1.0))
-        self._block = _KernelBlock(_kernel_kind, A1, A2, kernel_config)
+        mode = _mode_override()
+        self._sym = None
+        if _same_points(A1, A2) and mode in ("auto", "sympack") and (
+            mode == "sympack" or _SymPackBlock.fits(A1.shape[0], 1, A1.dtype, A1.device)
+        ):
+            self._sym = _SymPackBlock(_kernel_kind, A1, kernel_config)
+            fwd = bwd = self._sym_matmat
+            self._block = None
+        else:
+            self._block = _KernelBlock(_kernel_kind, A1, A2, kernel_config)
+            fwd, bwd = self._block.matmat, self._block.rmatmat
         super().__init__(
             device=A1.device,
             shape=torch.Size((A1.shape[0], A2.shape[0])),
-            matvec=self._block.matmat,
-            rmatvec=self._block.rmatmat,
-            matmat=self._block.matmat,
-            rmatmat=self._block.rmatmat,
+            matvec=fwd, rmatvec=bwd, matmat=fwd, rmatmat=bwd,
             dtype=A1.dtype,
         )
 
@@ -134,8 +217,23 @@ class _KernelLinOp(TwoSidedLinOp, ScaleMixin):
     A2 = property(lambda self: self._A2)
     kernel_config = property(lambda self: self._kernel_config)
 
+    @property
+    def storage_mode(self) -> str:
+        if self._sym is not None:
+            return "sympack"
+        return "materialize" if self._block.materialised else "matrix_free"
+
+    def _sym_matmat(self, x, diag_shift=0.0):
+        cols = 1 if x.ndim == 1 else x.shape[1]
+        if cols <= _SYM_MAX_COLS:
+            return self._sym.partial_matmat(x, diag_shift=diag_shift)
+        y = self._sym.rows_matmat_wide(x, 0, self.shape[0])
+        return y + diag_shift * x if diag_shift != 0.0 else y
+
     # fused "A @ X + shift * X" used by the solvers (saves one pass over X)
     def _rk_shifted_matmat(self, X, shift):
+        if self._sym is not None:
+            return self._sym_matmat(X, diag_shift=shift)
         return self._block.matmat(X, diag_shift=shift, row0=0)
 
     def _get_kernel_linop(self, idx1=None, idx2=None) -> LinOp:
@@ -233,11 +331,23 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
             A2[lo:hi].to(dev) if owned(i) else None
             for i, ((lo, hi), dev) in enumerate(zip(self._A2_bounds, self._shard_devices))
         ]
+        # symmetric data + one shard per process: strip-packed triangle, strips dealt cyclically
+        mode = _mode_override()
+        nshards = len(self._A1_bounds)
+        my_dev = self._shard_devices[rank if spmd else 0] if nshards else None
+        self._sym = None
+        if (use_full_kernel and _same_points(A1, A2) and mode in ("auto", "sympack")
+                and (spmd or nshards == 1)
+                and (mode == "sympack" or _SymPackBlock.fits(n1, size if spmd else 1, A1.dtype, my_dev))):
+            self._sym = _SymPackBlock(
+                _kernel_kind, A1.to(my_dev), kernel_config.to(my_dev),
+                first=rank if spmd else 0, stride=size if spmd else 1,
+            )
         shards = []
         for i, ((lo, hi), dev) in enumerate(zip(self._A1_bounds, self._shard_devices)):
             shape = torch.Size((hi - lo, n2))
-            if not owned(i):
-                shards.append(_RemoteShard(dev, shape, A1.dtype))
+            if not owned(i) or self._sym is not None:
+                shards.append(_RemoteShard(dev, shape, A1.dtype))  # shape bookkeeping only
             elif use_full_kernel:
                 shards.append(_KernelShard(_kernel_kind, A1[lo:hi], A2, kernel_config, dev))
             else:
@@ -290,8 +400,55 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
         ids = self._local_ids()
         return self._shard_devices[ids[0] if ids else 0]
 
+    @property
+    def storage_mode(self) -> str:
+        if self._sym is not None:
+            return "sympack"
+        ids = self._local_ids()
+        shard = self._A[ids[0]] if ids else None
+        if isinstance(shard, _KernelShard):
+            return "materialize" if shard._block.materialised else "matrix_free"
+        return "oracle_only"
+
+    def _sym_full_matmat(self, X_full: torch.Tensor) -> torch.Tensor:
+        """K @ X (all rows) from the packed strips: local partial, summed over ranks."""
+        X_full = X_full.to(self._sym.X.device)
+        part = self._sym.partial_matmat(X_full)
+        if self._spmd:
+            _dist.all_reduce_sum(part, self._group)
+        return part
+
+    def _matvec(self, w: torch.Tensor) -> torch.Tensor:
+        if self._sym is None:
+            return super()._matvec(w)
+        cols = 1 if w.ndim == 1 else w.shape[1]
+        if cols <= _SYM_MAX_COLS:
+            return self._sym_full_matmat(w).to(w.device)
+        lo, hi = self.row_range
+        mine = self._sym.rows_matmat_wide(w.to(self._sym.X.device), lo, hi)
+        if self._spmd:
+            mine = _dist.all_gather_rows(mine, self.shape[0], self._group)
+        return mine.to(w.device)
+
+    def _rmatvec(self, w: torch.Tensor) -> torch.Tensor:
+        return self._matvec(w) if self._sym is not None else super()._rmatvec(w)
+
+    @property
+    def T(self):
+        return self if self._sym is not None else super().T
+
     def local_matmat(self, X_full: torch.Tensor, diag_shift: float = 0.0) -> torch.Tensor:
         """K[rows_i, :] @ X_full (+ diag_shift * X_full[rows_i]) -> local row block."""
+        if self._sym is not None:
+            lo, hi = self.row_range
+            cols = 1 if X_full.ndim == 1 else X_full.shape[1]
+            if cols <= _SYM_MAX_COLS:
+                if not self._spmd:  # one shard: the kernel applies the shift itself
+                    return self._sym.partial_matmat(X_full.to(self._sym.X.device), diag_shift=diag_shift)
+                Y = self._sym_full_matmat(X_full)[lo:hi]
+            else:
+                Y = self._sym.rows_matmat_wide(X_full.to(self._sym.X.device), lo, hi)
+            return Y + diag_shift * X_full[lo:hi].to(Y.device) if diag_shift != 0.0 else Y
         ids = self._local_ids()
         if not ids:
             k = () if X_full.ndim == 1 else (X_full.shape[1],)
@@ -306,6 +463,10 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
         if self._spmd or len(self._A) != 1:
             return None  # generic path (A @ X, then + shift * X)
         return self.local_matmat(X, diag_shift=shift).to(X.device)
+
+    @property
+    def row_range_all(self):
+        return self._A1_bounds
 
     # -- oracles ---------------------------------------------------------------------------
     def row_oracle(self, blk: torch.Tensor) -> _DistributedLinOp:
@@ -361,4 +522,6 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
         for op in self.kernel_ops:
             if hasattr(op, "_clear_cache"):
                 op._clear_cache()
+        if self._sym is not None:
+            self._sym.release()
         super().shutdown()

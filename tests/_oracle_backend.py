@@ -26,6 +26,28 @@ class OracleBackend:
     def kernel_matmat(self, kind, X1, X2, lengthscale, V, scale=1.0, idx1=None, idx2=None):
         return ok.kernel_matmat(kind, X1, X2, lengthscale, V, scale, idx1=idx1, idx2=idx2)
 
+    # sympack stand-in: keeps the dense matrix restricted to this rank's strips (upper part)
+    def sympack_materialize(self, kind, X, lengthscale, scale=1.0, first=0, stride=1):
+        n = X.shape[0]
+        W = 256 if X.dtype == torch.float32 else 128
+        K = ok.kernel_matrix(kind, X, X, lengthscale, scale)
+        keep = torch.zeros_like(K)
+        for s in range(first, -(-n // W), stride):
+            lo, hi = s * W, min(n, (s + 1) * W)
+            keep[:hi, lo:hi] = K[:hi, lo:hi]
+        return keep.reshape(-1)
+
+    def symm_matmat(self, Kp, n, V, alpha=1.0, diag_shift=0.0, first=0, stride=1, tag=None):
+        U = Kp.reshape(n, n)
+        W = 256 if U.dtype == torch.float32 else 128
+        V2, sq = _two_d(V)
+        Y = U @ V2  # row contributions of every stored entry
+        for s in range(first, -(-n // W), stride):  # column contributions from above the diagonal block
+            lo, hi = s * W, min(n, (s + 1) * W)
+            Y[lo:hi] += U[:lo, lo:hi].T @ V2[:lo]
+        Y = alpha * Y + diag_shift * V2
+        return Y[:, 0] if sq else Y
+
     def matmat(self, A, V, alpha=1.0, beta=0.0, C=None, diag_shift=0.0, row0=0, tag=None):
         V2, sq = _two_d(V)
         Y = alpha * (A @ V2)

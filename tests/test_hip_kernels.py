@@ -214,3 +214,33 @@ def test_bad_arguments_raise(be):
         be.kernel_materialize("rbf", A, A, -1.0)
     with pytest.raises(ValueError):
         be.matmat(A.to(torch.float16), torch.zeros(4, 1, device=dev(), dtype=torch.float16))
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern32"])
+@pytest.mark.parametrize("n", [1, 63, 256, 257, 700, 1024, 1025, 3000])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 7])
+def test_sympack_product_matches_dense(be, prec, kind, n, k):
+    """Strip-packed symmetric storage: y = K v from half the bytes equals the dense product, for
+    every strip distribution (first, stride) - partial sums of the ranks add up to K v."""
+    dt = DTYPES[prec]
+    gen = torch.Generator().manual_seed(n + k)
+    d = 5
+    X = torch.randn(n, d, dtype=dt, generator=gen) / d**0.5
+    V = torch.randn(n, k, dtype=dt, generator=gen)
+    K = ok.kernel_matrix(kind, X.double(), X.double(), 0.8, 1.5)
+    want = K @ V.double()
+    Xd, Vd = X.to(dev()), V.to(dev())
+    for stride in (1, 2, 3):
+        total = torch.zeros(n, k, dtype=torch.float64)
+        for first in range(stride):
+            Kp = be.sympack_materialize(kind, Xd, 0.8, scale=1.5, first=first, stride=stride)
+            part = be.symm_matmat(Kp, n, Vd, first=first, stride=stride)
+            total += part.cpu().double()
+        assert rel_err(total, want) < LIM[dt] * 5, (stride,)
+    Kp = be.sympack_materialize(kind, Xd, 0.8, scale=1.5)
+    got = be.symm_matmat(Kp, n, Vd, alpha=-2.0, diag_shift=0.25)
+    assert rel_err(got.cpu(), -2.0 * want + 0.25 * V.double()) < LIM[dt] * 5
+    got1 = be.symm_matmat(Kp, n, Vd[:, 0].contiguous())
+    assert got1.ndim == 1 and rel_err(got1.cpu(), want[:, 0]) < LIM[dt] * 5
+    # reproducible bit for bit
+    assert torch.equal(be.symm_matmat(Kp, n, Vd), be.symm_matmat(Kp, n, Vd))

@@ -47,6 +47,20 @@ def main():
                     gb = (m * n + n * k + m * k) * es / 1e9
                     print(f"skinny {dt} m={m} n={n} k={k}: {med*1e3:.3f} ms  {gb/med:.0f} GB/s (best {gb/best:.0f})", flush=True)
                 del A
+    if "symm" in what:
+        for dt in (torch.float32, torch.float64):
+            es = 4 if dt == torch.float32 else 8
+            X = torch.randn(n, 64, dtype=dt, device=dev) / 8
+            Kp = be.sympack_materialize("rbf", X, 1.0)
+            torch.cuda.synchronize()
+            med, best = timeit(lambda: be.sympack_materialize("rbf", X, 1.0), reps=3, warm=1)
+            print(f"sympack materialize {dt} n={n}: {med*1e3:.2f} ms  ({Kp.numel()*es/1e9:.2f} GB packed)", flush=True)
+            for k in (1, 2, 4):
+                V = torch.randn(n, k, dtype=dt, device=dev)
+                med, best = timeit(lambda: be.symm_matmat(Kp, n, V, diag_shift=0.1))
+                gb = Kp.numel() * es / 1e9
+                print(f"symm {dt} n={n} k={k}: {med*1e3:.3f} ms  {gb/med:.0f} GB/s of packed bytes = {n*n*es/1e9/med:.0f} GB/s dense-equivalent", flush=True)
+            del Kp
     if "skinny_t" in what:
         for r, k in ((512, 1), (512, 4), (100, 10)):
             U = torch.randn(2 * n, r, dtype=torch.float32, device=dev)
