@@ -123,7 +123,7 @@ def test_fullsize_fused_product_properties(be, full_problem):
     assert float((part - whole).norm() / whole.norm()) < 1e-5
     idx = torch.arange(bounds[3][0], bounds[3][0] + 4096, device=DEV)
     gathered = be.kernel_matmat("rbf", Xd, Xd, 1.0, vd, idx1=idx)
-    assert float((gathered - Kv[idx]).norm() / Kv[idx].norm()) < 1e-6
+    assert float((gathered - Kv[idx]).norm() / Kv[idx].norm()) < 1e-5
     # (5) positive-definiteness sanity: v^T K v > 0
     assert bool(((vd.double() * Kv.double()).sum(0) > 0).all())
     assert n == 200_000
