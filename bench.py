@@ -121,10 +121,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if os.environ.get("RK_BENCH_ONE_GPU", "0") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        td.init_process_group("nccl", device_id=dev)
+        # RK_BENCH_BACKEND=gloo + RK_BENCH_ONE_GPU=1 rehearse the multi-rank path on a one-GPU box
+        backend = os.environ.get("RK_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=dev)
+        else:
+            td.init_process_group(backend)
 
     from rlaopt_amd import sketches
     from rlaopt_amd.kernels import DistributedRBFLinOp, KernelConfig
@@ -158,6 +165,7 @@ def main():
     pcfg = NystromConfig(rank=r, rho=reg, sketch="gauss", damping_mode="adaptive")
     with sketches.inject(Omd):
         solver = PCG(system, torch.zeros(n, k, device=dev), pcfg, dev)
+    system._active_solver = solver  # what LinSys.solve does: metric and next step share a pass
     sync()
     t_pre = time.time() - t0
     del Omd

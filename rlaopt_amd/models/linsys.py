@@ -86,6 +86,7 @@ class LinSys(Model):
         self._mask = torch.ones(self._B.shape[1], dtype=torch.bool)
         self._ctx = None
         self._B_norms = None
+        self._active_solver = None  # lets the metric share one operator pass with the solver
 
     A = property(lambda self: self._A)
     B = property(lambda self: self._B)
@@ -115,7 +116,11 @@ class LinSys(Model):
         ctx = self._exec_context()
         if self._B_norms is None:
             self._B_norms = ctx.col_norms(ctx.B)
-        abs_res = ctx.col_norms(ctx.residual(ctx.take_rows(W)))
+        W_rows = ctx.take_rows(W)
+        fused = getattr(self._active_solver, "_fused_log_product", None)
+        AW = fused(W_rows) if fused is not None else None
+        R = ctx.residual(W_rows) if AW is None else ctx.B - AW
+        abs_res = ctx.col_norms(R)
         dt = self._B.dtype
         return {"abs_res": abs_res.to(dt), "rel_res": (abs_res / self._B_norms).to(dt)}
 
@@ -145,6 +150,7 @@ class LinSys(Model):
             ),
         )
         solver = _get_solver(model=self, W_init=W_init, solver_config=solver_config)
+        self._active_solver = solver
         return self._train(
             logger=logger,
             termination_fn=lambda m: self._check_termination_criteria(m, atol, rtol),

@@ -60,6 +60,7 @@ class PCG(Solver):
         Z = self.P._inv @ self._Rc
         self._Pc = Z.clone()
         self.RZ = ctx.gram(self._Rc, Z)  # k x k float64 on the device
+        self._AP_next = None  # (A + reg I) P computed ahead of time by _fused_log_product
 
     # reference attribute names, as full arrays (debug / tests)
     @property
@@ -81,6 +82,22 @@ class PCG(Solver):
         P._update_damping(baseline_rho=self.system.reg)
         return P
 
+    # widest fused product that still streams the operator at full rate (see _fused_log_product)
+    _FUSE_MAX_COLS = 4
+
+    def _fused_log_product(self, W_rows: torch.Tensor):
+        """(A + reg I) [P, W] in ONE pass over the operator on a logging iteration: the W part
+        feeds the true-residual metric (the reference spends a whole extra product on it,
+        models/linsys.py:96-99), the P part is kept for the next step, which then skips its
+        own product.  Returns (A + reg I) W for the local rows, or None when the combined
+        width would leave the fast streaming kernels."""
+        ka = len(self._active)
+        if ka == 0 or ka + W_rows.shape[1] > self._FUSE_MAX_COLS or self._AP_next is not None:
+            return None
+        Y = self._ctx.shifted_matmat(torch.cat([self._Pc, W_rows], dim=1))
+        self._AP_next = Y[:, :ka].contiguous()
+        return Y[:, ka:]
+
     def _compact(self, mask) -> None:
         want = [j for j in range(self._k) if bool(mask[j])]
         want = [j for j in want if j in self._active]  # a finished column never restarts
@@ -92,6 +109,8 @@ class PCG(Solver):
         self._Wc = self._Wc[:, idx].contiguous()
         self._Rc = self._Rc[:, idx].contiguous()
         self._Pc = self._Pc[:, idx].contiguous()
+        if self._AP_next is not None:
+            self._AP_next = self._AP_next[:, idx].contiguous()
         self.RZ = self.RZ[idx][:, idx].contiguous()
         self._active = want
 
@@ -103,7 +122,9 @@ class PCG(Solver):
         if not self._active:
             return
         be, ctx = self._be, self._ctx
-        AP = ctx.shifted_matmat(self._Pc)            # (A + reg I) P, local rows
+        AP, self._AP_next = self._AP_next, None
+        if AP is None:
+            AP = ctx.shifted_matmat(self._Pc)        # (A + reg I) P, local rows
         PAP = ctx.gram(self._Pc, AP)
         alpha = be.small_solve(PAP, self.RZ)
         be.pcg_update_wr(self._Wc, self._Rc, self._Pc, AP, alpha)
