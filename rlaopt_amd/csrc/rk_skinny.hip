@@ -356,23 +356,27 @@ skinny_t_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
 }
 
 // out[e] = alpha * sum_s part[s][e] + beta * C[e]; the S partials are summed in float64 by
-// 4 slices per output, combined in a fixed order through LDS.
+// 16 slices per output (64 outputs x 16 slices per workgroup), combined in a fixed order
+// through LDS.
 template <typename T, typename TO>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 skinny_t_finish(const T* __restrict__ part, int64_t S, int64_t n, int K, double alpha, double beta,
                 const T* __restrict__ C, int64_t ldc, TO* __restrict__ Y, int64_t ldy) {
-    __shared__ double red[4][64];
+    constexpr int NS = 16;
+    __shared__ double red[NS][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t e = (int64_t)blockIdx.x * 64 + tx;
     const int64_t total = n * K;
     double s = 0.0;
     if (e < total) {
-        for (int64_t t = ty; t < S; t += 4) s += (double)part[t * total + e];
+        for (int64_t t = ty; t < S; t += NS) s += (double)part[t * total + e];
     }
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && e < total) {
-        s = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
+        s = 0.0;
+#pragma unroll
+        for (int y = 0; y < NS; ++y) s += red[y][tx];
         const int64_t jrow = e / K;
         const int c = (int)(e - jrow * K);
         double y = alpha * s;
@@ -683,10 +687,10 @@ static int matmat_skinny_t_impl(const T* A, int64_t m, int64_t n, int64_t lda, c
     const int64_t total = n * k;
     dim3 fgrid((unsigned)ceil_div(total, 64));
     if (out_f64)
-        hipLaunchKernelGGL((skinny_t_finish<T, double>), fgrid, dim3(256), 0, st, part, p.S, n,
+        hipLaunchKernelGGL((skinny_t_finish<T, double>), fgrid, dim3(1024), 0, st, part, p.S, n,
                            (int)k, alpha, beta, C, ldc, static_cast<double*>(Y), ldy);
     else
-        hipLaunchKernelGGL((skinny_t_finish<T, T>), fgrid, dim3(256), 0, st, part, p.S, n, (int)k,
+        hipLaunchKernelGGL((skinny_t_finish<T, T>), fgrid, dim3(1024), 0, st, part, p.S, n, (int)k,
                            alpha, beta, C, ldc, static_cast<T*>(Y), ldy);
     return launch_status("rk_matmat_skinny_t(finish)");
 }

@@ -237,31 +237,50 @@ symm_strip_kernel(const T* __restrict__ Kp, SymLayout L, const T* __restrict__ V
 
 // Y[i][c] = alpha * (row parts of every local strip that stores row i
 //                    + column parts of the local strip that owns column i) + shift * V[i][c]
+// 64 outputs x 16 slices per workgroup: slice y adds the terms y, y + 16, ... (row parts first,
+// then column parts, one combined index); slices are combined in a fixed order through LDS.
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 symm_finish_kernel(SymLayout L, int K, const T* __restrict__ Prow, const T* __restrict__ Pcol,
                    int64_t max_items, T alpha, T shift, const T* __restrict__ V, int64_t ldv,
                    T* __restrict__ Y, int64_t ldy) {
+    constexpr int NS = 16;
+    __shared__ T red[NS][64];
     const int W = L.W;
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= L.n * K) return;
-    const int64_t i = e / K;
-    const int c = (int)(e - i * K);
-    const int64_t blk = i / W;
-    const int64_t T_loc = L.strips_local();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + tx;
+    const bool live = e < L.n * K;
     T sum = T(0);
-    int64_t t0 = blk <= L.first ? 0 : (blk - L.first + L.stride - 1) / L.stride;
-    for (int64_t t = t0; t < T_loc; ++t) sum += Prow[(L.row_offset(t) + i) * K + c];
-    if (blk >= L.first && (blk - L.first) % L.stride == 0) {
-        const int64_t t = (blk - L.first) / L.stride;
-        const int64_t items = (L.rows(t) + ITEM_ROWS - 1) / ITEM_ROWS;
+    int64_t i = 0;
+    int c = 0;
+    if (live) {
+        i = e / K;
+        c = (int)(e - i * K);
+        const int64_t blk = i / W;
+        const int64_t T_loc = L.strips_local();
+        const int64_t t0 = blk <= L.first ? 0 : (blk - L.first + L.stride - 1) / L.stride;
+        const int64_t nrow = T_loc > t0 ? T_loc - t0 : 0;
+        int64_t tc = -1, items = 0;
+        if (blk >= L.first && (blk - L.first) % L.stride == 0) {
+            tc = (blk - L.first) / L.stride;
+            items = (L.rows(tc) + ITEM_ROWS - 1) / ITEM_ROWS;
+        }
         const int64_t jloc = i - blk * W;
-        for (int64_t it = 0; it < items; ++it)
-            sum += Pcol[((t * max_items + it) * W + jloc) * K + c];
+        for (int64_t u = ty; u < nrow + items; u += NS) {
+            if (u < nrow) sum += Prow[(L.row_offset(t0 + u) + i) * K + c];
+            else sum += Pcol[((tc * max_items + (u - nrow)) * W + jloc) * K + c];
+        }
     }
-    T y = alpha * sum;
-    if (shift != T(0)) y += shift * V[i * ldv + c];
-    Y[i * ldy + c] = y;
+    red[ty][tx] = sum;
+    __syncthreads();
+    if (ty == 0 && live) {
+        sum = T(0);
+#pragma unroll
+        for (int y = 0; y < NS; ++y) sum += red[y][tx];
+        T y = alpha * sum;
+        if (shift != T(0)) y += shift * V[i * ldv + c];
+        Y[i * ldy + c] = y;
+    }
 }
 
 template <typename T>
@@ -332,7 +351,7 @@ static int symm_matmat_impl(const T* Kp, int64_t n, int64_t first, int64_t strid
         int rc = launch_status("rk_symm_matmat");
         if (rc != RK_OK) return rc;
     }
-    hipLaunchKernelGGL((symm_finish_kernel<T>), dim3((unsigned)ceil_div(n * k, 256)), dim3(256), 0,
+    hipLaunchKernelGGL((symm_finish_kernel<T>), dim3((unsigned)ceil_div(n * k, 64)), dim3(1024), 0,
                        st, L, (int)k, Prow, Pcol, max_items, (T)alpha, (T)shift, V, ldv, Y, ldy);
     return launch_status("rk_symm_matmat(finish)");
 }

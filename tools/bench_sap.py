@@ -33,7 +33,7 @@ def main():
     B = torch.randn(n, k, dtype=torch.float64, generator=g).float().to(dev)
     reg = 1e-2
     os.environ["RK_KERNEL_MODE"] = "matrix_free"  # SAP only touches the oracles
-    A = DistributedRBFLinOp(X, X, KernelConfig(lengthscale=1.0), devices={dev}, use_full_kernel=False)
+    A = DistributedRBFLinOp(X, X, KernelConfig(lengthscale=1.0), devices={dev})  # matrix-free: no n x n block
     system = LinSys(A, B, reg=reg, A_row_oracle=A.row_oracle, A_blk_oracle=A.blk_oracle)
     cfg = SAPConfig(device=dev, max_iters=300, atol=1e-6, rtol=1e-6,
                     precond_config=NystromConfig(rank=args.rank, rho=reg), blk_sz=n // 100,
