@@ -112,9 +112,9 @@ skinny_nn_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int c = 0; c < K; ++c) acc[r][c] = wave_sum(acc[r][c]);
+        for (int c = 0; c < K; ++c) acc[r][c] = wave_total_lane63(acc[r][c]);
 
-    if (lane == 0) {
+    if (lane == 63) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int64_t row = r0 + r;
@@ -238,8 +238,8 @@ skinny_nn_lds_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int c = 0; c < K; ++c) acc[r][c] = wave_sum(acc[r][c]);
-    if (lane == 0) {
+        for (int c = 0; c < K; ++c) acc[r][c] = wave_total_lane63(acc[r][c]);
+    if (lane == 63) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int64_t row = r0 + r;

@@ -105,32 +105,6 @@ sympack_materialize_kernel(int kind, const T* __restrict__ X, int64_t ldx, int64
 }
 
 // ------------------------------------------------------------------------------------------
-// wave total in lane 63 without LDS: 4 DPP adds inside each 16-lane row, then row broadcasts
-// ------------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_fetch(float v) {
-    return __builtin_bit_cast(
-        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
-}
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_fetch(double v) {
-    const long long bits = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)bits, CTRL, ROW_MASK, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, ROW_MASK, 0xF, false);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-template <typename T>
-__device__ __forceinline__ T wave_total_lane63(T v) {
-    v += dpp_fetch<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-    v += dpp_fetch<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-    v += dpp_fetch<0x141, 0xF>(v);  // row_half_mirror
-    v += dpp_fetch<0x140, 0xF>(v);  // row_mirror: every lane holds its 16-lane row sum
-    v += dpp_fetch<0x142, 0xA>(v);  // row_bcast15 -> rows 1 and 3
-    v += dpp_fetch<0x143, 0xC>(v);  // row_bcast31 -> rows 2 and 3: lane 63 holds the total
-    return v;
-}
-
-// ------------------------------------------------------------------------------------------
 // the strip product
 // ------------------------------------------------------------------------------------------
 template <typename T, int K>
