@@ -29,6 +29,7 @@ import torch
 from .. import dist as _dist
 from ..ops import get_backend
 from ..sketches import get_sketch
+from ..utils import small_host_lapack
 from .configs import NystromConfig
 from .enums import _DampingMode
 from .preconditioner import Preconditioner
@@ -69,26 +70,28 @@ class Nystrom(Preconditioner):
 
         shift = torch.finfo(A.dtype).eps * torch.trace(core)  # eps of the WORKING dtype
         core = core + shift * torch.eye(rank_r, dtype=torch.float64)
-        L = torch.linalg.cholesky(core, upper=False)
-        H = torch.linalg.solve_triangular(L, gram, upper=False)
-        H = torch.linalg.solve_triangular(L, H.T.contiguous(), upper=False)  # L^-1 G L^-T
-        H = 0.5 * (H + H.T)
-        evals, V = torch.linalg.eigh(H)
-        evals, V = evals.flip(0), V.flip(1)  # descending, like singular values
-        sig2 = evals.clamp_min(0.0)
-        sigma = sig2.sqrt()
-        tiny = sigma[0] * 1e-150 if sigma[0] > 0 else 0.0
-        inv_sigma = torch.where(sigma > tiny, 1.0 / sigma.clamp_min(1e-300), torch.zeros_like(sigma))
-        M = torch.linalg.solve_triangular(L.T.contiguous(), V, upper=True) * inv_sigma[None, :]
+        with small_host_lapack(rank_r):
+            L = torch.linalg.cholesky(core, upper=False)
+            H = torch.linalg.solve_triangular(L, gram, upper=False)
+            H = torch.linalg.solve_triangular(L, H.T.contiguous(), upper=False)  # L^-1 G L^-T
+            H = 0.5 * (H + H.T)
+            evals, V = torch.linalg.eigh(H)
+            evals, V = evals.flip(0), V.flip(1)  # descending, like singular values
+            sig2 = evals.clamp_min(0.0)
+            sigma = sig2.sqrt()
+            tiny = sigma[0] * 1e-150 if sigma[0] > 0 else 0.0
+            inv_sigma = torch.where(sigma > tiny, 1.0 / sigma.clamp_min(1e-300), torch.zeros_like(sigma))
+            M = torch.linalg.solve_triangular(L.T.contiguous(), V, upper=True) * inv_sigma[None, :]
         U = be.gemm(Y, M.to(device=device, dtype=A.dtype))
         del Y
         # one symmetric (Loewdin) re-orthonormalisation: U <- U (U^T U)^-1/2
         G2 = be.gram_tn(U, U)
         if self._sharded:
             _dist.all_reduce_sum(G2, self._group)
-        w, Q = torch.linalg.eigh(G2.cpu())
-        inv_sqrt = torch.where(w > 1e-8, w.clamp_min(1e-300).rsqrt(), torch.zeros_like(w))
-        fix = (Q * inv_sqrt[None, :]) @ Q.T
+        with small_host_lapack(rank_r):
+            w, Q = torch.linalg.eigh(G2.cpu())
+            inv_sqrt = torch.where(w > 1e-8, w.clamp_min(1e-300).rsqrt(), torch.zeros_like(w))
+            fix = (Q * inv_sqrt[None, :]) @ Q.T
         self.U = be.gemm(U, fix.to(device=device, dtype=A.dtype))
         self.S = (sig2 - shift).clamp_min(0.0).to(device=device, dtype=A.dtype)
         self._M = None
@@ -132,8 +135,9 @@ class Nystrom(Preconditioner):
             Minv = torch.zeros((r, r), dtype=torch.float64)
             if keep.numel():
                 small = rho * torch.diag(1.0 / S64[keep]) + UtU[keep][:, keep]
-                Lk = torch.linalg.cholesky(0.5 * (small + small.T))
-                Minv[keep[:, None], keep[None, :]] = torch.cholesky_inverse(Lk)
+                with small_host_lapack(r):
+                    Lk = torch.linalg.cholesky(0.5 * (small + small.T))
+                    Minv[keep[:, None], keep[None, :]] = torch.cholesky_inverse(Lk)
                 self.L = Lk.to(device=dev, dtype=dt)
             self._M = Minv.to(device=dev, dtype=dt)
         else:

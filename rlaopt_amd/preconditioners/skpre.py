@@ -13,6 +13,7 @@ import torch
 
 from ..ops import get_backend
 from ..sketches import get_sketch
+from ..utils import small_host_lapack
 from .preconditioner import Preconditioner
 
 
@@ -38,8 +39,9 @@ class SkPre(Preconditioner):
         del Y  # the reference frees it too (skpre.py:142-153)
         if self.config.rho != 0:
             G.diagonal().add_(self.config.rho)
-        L = torch.linalg.cholesky(G, upper=False)
-        Linv = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=torch.float64), upper=False)
+        with small_host_lapack(G.shape[0]):
+            L = torch.linalg.cholesky(G, upper=False)
+            Linv = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=torch.float64), upper=False)
         self.L = L.to(device=device, dtype=A.dtype)
         self._Linv = Linv.to(device=device, dtype=A.dtype)
 

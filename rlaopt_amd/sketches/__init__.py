@@ -26,7 +26,7 @@ import torch
 from .. import dist as _dist
 from ..linops.base import _BaseLinOp
 from ..ops import get_backend
-from ..utils import _is_pos_int
+from ..utils import _is_pos_int, small_host_lapack
 
 __all__ = ["get_sketch", "inject"]
 
@@ -151,10 +151,11 @@ class Ortho(Sketch):
         Q = _device_randn(self.d, self.s, self.dtype, self.device)
         for _ in range(2):
             G = be.gram_tn(Q, Q)  # float64 (s x s)
-            R = torch.linalg.cholesky(G.cpu(), upper=True)
-            Rinv = torch.linalg.solve_triangular(
-                R, torch.eye(self.s, dtype=torch.float64), upper=True
-            )
+            with small_host_lapack(self.s):
+                R = torch.linalg.cholesky(G.cpu(), upper=True)
+                Rinv = torch.linalg.solve_triangular(
+                    R, torch.eye(self.s, dtype=torch.float64), upper=True
+                )
             Q = be.gemm(Q, Rinv.to(device=self.device, dtype=self.dtype))
         return Q.T.contiguous() if self.mode is _SketchSide.LEFT else Q
 
