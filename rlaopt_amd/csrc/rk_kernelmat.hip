@@ -19,15 +19,15 @@
 
 namespace rk {
 
-template <typename T, bool L1>
+template <typename T, bool L1, int DCV>
 __global__ void __launch_bounds__(256)
 kmat_materialize_kernel(int kind, const T* __restrict__ X1, int64_t n1, int64_t ldx1,
                         const int64_t* __restrict__ idx1, const T* __restrict__ X2, int64_t n2,
                         int64_t ldx2, const int64_t* __restrict__ idx2, int64_t d, T w,
                         const T* __restrict__ ell_vec, T scale, T* __restrict__ K, int64_t ldk,
                         int vec_store) {
-    __shared__ T xs[DC][LDP];
-    __shared__ T ys[DC][LDP];
+    __shared__ T xs[DCV][LDP];
+    __shared__ T ys[DCV][LDP];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int64_t i0 = (int64_t)blockIdx.y * TM, j0 = (int64_t)blockIdx.x * TN;
     T acc[4][4];
@@ -35,12 +35,12 @@ kmat_materialize_kernel(int kind, const T* __restrict__ X1, int64_t n1, int64_t 
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[r][q] = T(0);
-    for (int64_t c0 = 0; c0 < d; c0 += DC) {
+    for (int64_t c0 = 0; c0 < d; c0 += DCV) {
         __syncthreads();
-        stage_panel<T>(xs, X1, n1, ldx1, idx1, i0, c0, d, ell_vec);
-        stage_panel<T>(ys, X2, n2, ldx2, idx2, j0, c0, d, ell_vec);
+        stage_panel<T, DCV>(xs, X1, n1, ldx1, idx1, i0, c0, d, ell_vec);
+        stage_panel<T, DCV>(ys, X2, n2, ldx2, idx2, j0, c0, d, ell_vec);
         __syncthreads();
-        tile_accumulate<T, L1>(xs, ys, ty, tx, acc);
+        tile_accumulate<T, L1>(xs, ys, ty, tx, acc, (int)((d - c0) < DCV ? (d - c0) : DCV));
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -66,7 +66,7 @@ kmat_materialize_kernel(int kind, const T* __restrict__ X1, int64_t n1, int64_t 
     }
 }
 
-template <typename T, bool L1, int KB>
+template <typename T, bool L1, int KB, int DCV>
 __global__ void __launch_bounds__(256)
 kmat_matmat_kernel(int kind, const T* __restrict__ X1, int64_t n1, int64_t ldx1,
                    const int64_t* __restrict__ idx1, const T* __restrict__ X2, int64_t n2,
@@ -74,8 +74,8 @@ kmat_matmat_kernel(int kind, const T* __restrict__ X1, int64_t n1, int64_t ldx1,
                    const T* __restrict__ ell_vec, T scale, const T* __restrict__ V, int k,
                    int64_t ldv, int64_t tiles_per_seg, T* __restrict__ part, T* __restrict__ Y,
                    int64_t ldy, int accumulate) {
-    __shared__ T xs[DC][LDP];
-    __shared__ T ys[DC][LDP];
+    __shared__ T xs[DCV][LDP];
+    __shared__ T ys[DCV][LDP];
     __shared__ T vs[TN][KB];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int64_t i0 = (int64_t)blockIdx.x * TM;
@@ -90,8 +90,8 @@ kmat_matmat_kernel(int kind, const T* __restrict__ X1, int64_t n1, int64_t ldx1,
         for (int c = 0; c < KB; ++c) y[r][c] = T(0);
 
     // the X1 panel is staged once when all features fit one chunk, else per (tile, chunk)
-    const bool one_chunk = (d <= DC);
-    if (one_chunk) stage_panel<T>(xs, X1, n1, ldx1, idx1, i0, 0, d, ell_vec);
+    const bool one_chunk = (d <= DCV);
+    if (one_chunk) stage_panel<T, DCV>(xs, X1, n1, ldx1, idx1, i0, 0, d, ell_vec);
     for (int64_t t = t_lo; t < t_hi; ++t) {
         const int64_t j0 = t * TN;
         T acc[4][4];
@@ -99,10 +99,10 @@ kmat_matmat_kernel(int kind, const T* __restrict__ X1, int64_t n1, int64_t ldx1,
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[r][q] = T(0);
-        for (int64_t c0 = 0; c0 < d; c0 += DC) {
+        for (int64_t c0 = 0; c0 < d; c0 += DCV) {
             __syncthreads();  // readers of the previous panels / V slice are done
-            if (!one_chunk) stage_panel<T>(xs, X1, n1, ldx1, idx1, i0, c0, d, ell_vec);
-            stage_panel<T>(ys, X2, n2, ldx2, idx2, j0, c0, d, ell_vec);
+            if (!one_chunk) stage_panel<T, DCV>(xs, X1, n1, ldx1, idx1, i0, c0, d, ell_vec);
+            stage_panel<T, DCV>(ys, X2, n2, ldx2, idx2, j0, c0, d, ell_vec);
             if (c0 == 0) {
                 // V slice for this column tile, zero padded to KB columns / past n2
                 for (int e = threadIdx.x; e < TN * KB; e += 256) {
@@ -112,7 +112,7 @@ kmat_matmat_kernel(int kind, const T* __restrict__ X1, int64_t n1, int64_t ldx1,
                 }
             }
             __syncthreads();
-            tile_accumulate<T, L1>(xs, ys, ty, tx, acc);
+            tile_accumulate<T, L1>(xs, ys, ty, tx, acc, (int)((d - c0) < DCV ? (d - c0) : DCV));
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -199,12 +199,12 @@ static int materialize_impl(int kind, const T* X1, int64_t n1, int64_t ldx1, con
     const T w = ell_vec ? T(1) : T(1.0 / ell);
     const int vec = aligned16(K) && (ldk % (16 / sizeof(T)) == 0);
     dim3 grid((unsigned)ceil_div(n2, TN), (unsigned)ceil_div(n1, TM));
-    if (kind == RK_LAPLACE)
-        hipLaunchKernelGGL((kmat_materialize_kernel<T, true>), grid, dim3(256), 0, st, kind, X1, n1,
-                           ldx1, idx1, X2, n2, ldx2, idx2, d, w, ell_vec, (T)scale, K, ldk, vec);
-    else
-        hipLaunchKernelGGL((kmat_materialize_kernel<T, false>), grid, dim3(256), 0, st, kind, X1,
-                           n1, ldx1, idx1, X2, n2, ldx2, idx2, d, w, ell_vec, (T)scale, K, ldk, vec);
+#define RK_MAT(L1V, DCVV)                                                                         \
+    hipLaunchKernelGGL((kmat_materialize_kernel<T, L1V, DCVV>), grid, dim3(256), 0, st, kind, X1,  \
+                       n1, ldx1, idx1, X2, n2, ldx2, idx2, d, w, ell_vec, (T)scale, K, ldk, vec)
+    if (kind == RK_LAPLACE) { if (d <= 32) RK_MAT(true, 32); else RK_MAT(true, 64); }
+    else { if (d <= 32) RK_MAT(false, 32); else RK_MAT(false, 64); }
+#undef RK_MAT
     return launch_status("rk_kernel_materialize");
 }
 
@@ -214,10 +214,17 @@ static void launch_kmatmat(int KB, dim3 grid, hipStream_t st, int kind, const T*
                            const int64_t* idx2, int64_t d, T w, const T* ell_vec, T scale,
                            const T* V, int k, int64_t ldv, int64_t tps, T* part, T* Y, int64_t ldy,
                            int accumulate) {
-#define RK_KM(KBV)                                                                                \
-    hipLaunchKernelGGL((kmat_matmat_kernel<T, L1, KBV>), grid, dim3(256), 0, st, kind, X1, n1,    \
-                       ldx1, idx1, X2, n2, ldx2, idx2, d, w, ell_vec, scale, V, k, ldv, tps, part, \
-                       Y, ldy, accumulate)
+#define RK_KM(KBV)                                                                                 \
+    do {                                                                                           \
+        if (d <= 32)                                                                               \
+            hipLaunchKernelGGL((kmat_matmat_kernel<T, L1, KBV, 32>), grid, dim3(256), 0, st, kind,  \
+                               X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d, w, ell_vec, scale, V, k,  \
+                               ldv, tps, part, Y, ldy, accumulate);                                \
+        else                                                                                       \
+            hipLaunchKernelGGL((kmat_matmat_kernel<T, L1, KBV, 64>), grid, dim3(256), 0, st, kind,  \
+                               X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d, w, ell_vec, scale, V, k,  \
+                               ldv, tps, part, Y, ldy, accumulate);                                \
+    } while (0)
     switch (KB) {
         case 1: RK_KM(1); break;
         case 2: RK_KM(2); break;

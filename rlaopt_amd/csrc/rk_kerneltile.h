@@ -8,7 +8,7 @@ namespace rk {
 
 constexpr int TM = 64;   // tile rows  (points of X1)
 constexpr int TN = 64;   // tile cols  (points of X2)
-constexpr int DC = 32;   // feature chunk staged per pass
+// feature chunk staged per pass: template parameter DCV (32 when d <= 32, else 64)
 constexpr int LDP = 68;  // padded panel stride (multiple of 4 for 16-B LDS reads)
 
 template <typename T>
@@ -47,7 +47,7 @@ __device__ __forceinline__ T kernel_value(int kind, T s, T w) {
 // Stage a 64-point x DC-feature panel into LDS, feature-major, optionally gathered through
 // idx and pre-scaled by 1/ell[c].  Lane -> point, wave -> 8-feature group: the LDS writes of
 // a wave are 64 consecutive words (conflict-free).
-template <typename T>
+template <typename T, int DCV>
 __device__ __forceinline__ void stage_panel(T (*dst)[LDP], const T* __restrict__ X, int64_t n,
                                             int64_t ldx, const int64_t* __restrict__ idx,
                                             int64_t p0, int64_t c0, int64_t d,
@@ -58,8 +58,8 @@ __device__ __forceinline__ void stage_panel(T (*dst)[LDP], const T* __restrict__
     const T* row = nullptr;
     if (p < n) row = X + (idx ? idx[p] : p) * ldx;
 #pragma unroll
-    for (int u = 0; u < DC / 4; ++u) {
-        const int c = cg * (DC / 4) + u;
+    for (int u = 0; u < DCV / 4; ++u) {
+        const int c = cg * (DCV / 4) + u;
         T v = T(0);
         if (row != nullptr && c0 + c < d) {
             v = row[c0 + c];
@@ -69,12 +69,13 @@ __device__ __forceinline__ void stage_panel(T (*dst)[LDP], const T* __restrict__
     }
 }
 
-// acc[r][q] += stat(x_r - y_q) over the staged chunk
+// acc[r][q] += stat(x_r - y_q) over the first `nc` features of the staged chunk (only the
+// features that exist are visited: d = 50 costs 50 steps, not a padded 64)
 template <typename T, bool L1>
 __device__ __forceinline__ void tile_accumulate(const T (*xs)[LDP], const T (*ys)[LDP], int ty,
-                                                int tx, T acc[4][4]) {
-#pragma unroll 8
-    for (int c = 0; c < DC; ++c) {
+                                                int tx, T acc[4][4], int nc) {
+#pragma unroll 4
+    for (int c = 0; c < nc; ++c) {
         T xa[4], yb[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { xa[e] = xs[c][ty * 4 + e]; yb[e] = ys[c][tx * 4 + e]; }

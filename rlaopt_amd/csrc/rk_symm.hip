@@ -55,15 +55,15 @@ constexpr int ITEM_ROWS = 1024;  // rows of a strip handled by one workgroup (4 
 // ------------------------------------------------------------------------------------------
 // materialise the packed triangle
 // ------------------------------------------------------------------------------------------
-template <typename T, bool L1>
+template <typename T, bool L1, int DCV>
 __global__ void __launch_bounds__(256)
 sympack_materialize_kernel(int kind, const T* __restrict__ X, int64_t ldx, int64_t d, T w,
                            const T* __restrict__ ell_vec, T scale, SymLayout L,
                            T* __restrict__ Kp) {
     constexpr int W = strip_width<T>();
     constexpr int CT = W / TN;  // column tiles per strip
-    __shared__ T xs[DC][LDP];
-    __shared__ T ys[DC][LDP];
+    __shared__ T xs[DCV][LDP];
+    __shared__ T ys[DCV][LDP];
     const int64_t t = blockIdx.y;
     const int64_t nrows = L.rows(t);
     const int64_t i0 = ((int64_t)blockIdx.x / CT) * TM;
@@ -76,12 +76,12 @@ sympack_materialize_kernel(int kind, const T* __restrict__ X, int64_t ldx, int64
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[r][q] = T(0);
-    for (int64_t c0 = 0; c0 < d; c0 += DC) {
+    for (int64_t c0 = 0; c0 < d; c0 += DCV) {
         __syncthreads();
-        stage_panel<T>(xs, X, L.n, ldx, nullptr, i0, c0, d, ell_vec);
-        stage_panel<T>(ys, X, L.n, ldx, nullptr, j0, c0, d, ell_vec);
+        stage_panel<T, DCV>(xs, X, L.n, ldx, nullptr, i0, c0, d, ell_vec);
+        stage_panel<T, DCV>(ys, X, L.n, ldx, nullptr, j0, c0, d, ell_vec);
         __syncthreads();
-        tile_accumulate<T, L1>(xs, ys, ty, tx, acc);
+        tile_accumulate<T, L1>(xs, ys, ty, tx, acc, (int)((d - c0) < DCV ? (d - c0) : DCV));
     }
     T* base = Kp + L.row_offset(t) * W;
 #pragma unroll
@@ -278,12 +278,12 @@ static int sympack_materialize_impl(int kind, const T* X, int64_t n, int64_t ldx
     const int64_t max_rows = L.rows(T_loc - 1);
     dim3 grid((unsigned)(ceil_div(max_rows, TM) * CT), (unsigned)T_loc);
     const T w = ell_vec ? T(1) : T(1.0 / ell);
-    if (kind == RK_LAPLACE)
-        hipLaunchKernelGGL((sympack_materialize_kernel<T, true>), grid, dim3(256), 0, st, kind, X,
-                           ldx, d, w, ell_vec, (T)scale, L, Kp);
-    else
-        hipLaunchKernelGGL((sympack_materialize_kernel<T, false>), grid, dim3(256), 0, st, kind, X,
-                           ldx, d, w, ell_vec, (T)scale, L, Kp);
+#define RK_SMAT(L1V, DCVV)                                                                        \
+    hipLaunchKernelGGL((sympack_materialize_kernel<T, L1V, DCVV>), grid, dim3(256), 0, st, kind, X, \
+                       ldx, d, w, ell_vec, (T)scale, L, Kp)
+    if (kind == RK_LAPLACE) { if (d <= 32) RK_SMAT(true, 32); else RK_SMAT(true, 64); }
+    else { if (d <= 32) RK_SMAT(false, 32); else RK_SMAT(false, 64); }
+#undef RK_SMAT
     return launch_status("rk_kernel_materialize_sympack");
 }
 

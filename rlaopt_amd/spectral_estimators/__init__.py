@@ -15,7 +15,13 @@ def randomized_powering(A, max_iters: int = 10, rtol: float = 1e-3, v0: torch.Te
     breaks for float64 operators under a float32 default)."""
     d = A.shape[0]
     if v0 is None:
-        v0 = torch.randn(d, device=A.device, dtype=getattr(A, "dtype", None))
+        dt = getattr(A, "dtype", None) or torch.get_default_dtype()
+        if torch.device(A.device).type == "cuda":
+            from ..sketches import _device_randn  # Philox kernel seeded from torch's generator
+
+            v0 = _device_randn(d, 1, dt, A.device)[:, 0]
+        else:
+            v0 = torch.randn(d, device=A.device, dtype=dt)
     v = v0 / torch.linalg.norm(v0, 2)
     i, err, sig, sig_new = 0, float("inf"), 0.0, None
     while i < max_iters and err > rtol * sig:
