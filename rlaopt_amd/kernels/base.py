@@ -282,15 +282,19 @@ class _KernelShard(TwoSidedLinOp):
         self._block.release()
 
 
-class _UnavailableShard(_BaseLinOp):
-    """Shard of an operator built with ``use_full_kernel=False`` (base.py:383-406): only the
-    oracles are usable, the full product is not."""
+def _oracle_only(_x):
+    raise RuntimeError("this operator was built with use_full_kernel=False: only "
+                       "row_oracle / blk_oracle are available")
 
-    def _matvec(self, x):
-        raise RuntimeError("this operator was built with use_full_kernel=False: only "
-                           "row_oracle / blk_oracle are available")
 
-    _matmat = _matvec
+class _UnavailableShard(TwoSidedLinOp):
+    """Shard of an operator built with ``use_full_kernel=False`` (base.py:383-406): a
+    ``TwoSidedLinOp`` placeholder, as in the reference; only the oracles are usable (the
+    reference's placeholder returns ``None`` from every product and fails later in
+    ``torch.cat`` - here the product raises a clear error)."""
+
+    def __init__(self, device, shape, dtype):
+        super().__init__(device, shape, _oracle_only, _oracle_only, _oracle_only, _oracle_only, dtype)
 
 
 def _sorted_devices(devices) -> list[torch.device]:
