@@ -40,7 +40,7 @@ kmat_materialize_kernel(int kind, const T* __restrict__ X1, int64_t n1, int64_t 
         stage_panel<T, DCV>(xs, X1, n1, ldx1, idx1, i0, c0, d, ell_vec);
         stage_panel<T, DCV>(ys, X2, n2, ldx2, idx2, j0, c0, d, ell_vec);
         __syncthreads();
-        tile_accumulate<T, L1>(xs, ys, ty, tx, acc, (int)((d - c0) < DCV ? (d - c0) : DCV));
+        tile_accumulate<T, L1, DCV>(xs, ys, ty, tx, acc, (int)((d - c0) < DCV ? (d - c0) : DCV));
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -112,7 +112,7 @@ kmat_matmat_kernel(int kind, const T* __restrict__ X1, int64_t n1, int64_t ldx1,
                 }
             }
             __syncthreads();
-            tile_accumulate<T, L1>(xs, ys, ty, tx, acc, (int)((d - c0) < DCV ? (d - c0) : DCV));
+            tile_accumulate<T, L1, DCV>(xs, ys, ty, tx, acc, (int)((d - c0) < DCV ? (d - c0) : DCV));
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {

@@ -72,21 +72,30 @@ __device__ __forceinline__ void stage_panel(T (*dst)[LDP], const T* __restrict__
 // acc[r][q] += stat(x_r - y_q) over the first `nc` features of the staged chunk (only the
 // features that exist are visited: d = 50 costs 50 steps, not a padded 64)
 template <typename T, bool L1>
+__device__ __forceinline__ void tile_step(const T (*xs)[LDP], const T (*ys)[LDP], int ty, int tx,
+                                          T acc[4][4], int c) {
+    T xa[4], yb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { xa[e] = xs[c][ty * 4 + e]; yb[e] = ys[c][tx * 4 + e]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const T df = xa[r] - yb[q];
+            if constexpr (L1) acc[r][q] += fabs(df);
+            else acc[r][q] += df * df;
+        }
+}
+
+template <typename T, bool L1, int DCV>
 __device__ __forceinline__ void tile_accumulate(const T (*xs)[LDP], const T (*ys)[LDP], int ty,
                                                 int tx, T acc[4][4], int nc) {
-#pragma unroll 4
-    for (int c = 0; c < nc; ++c) {
-        T xa[4], yb[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { xa[e] = xs[c][ty * 4 + e]; yb[e] = ys[c][tx * 4 + e]; }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const T df = xa[r] - yb[q];
-                if constexpr (L1) acc[r][q] += fabs(df);
-                else acc[r][q] += df * df;
-            }
+    if (nc == DCV) {  // full chunk: compile-time trip count
+#pragma unroll 8
+        for (int c = 0; c < DCV; ++c) tile_step<T, L1>(xs, ys, ty, tx, acc, c);
+    } else {
+#pragma unroll 2
+        for (int c = 0; c < nc; ++c) tile_step<T, L1>(xs, ys, ty, tx, acc, c);
     }
 }
 

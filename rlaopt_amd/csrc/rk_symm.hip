@@ -81,7 +81,7 @@ sympack_materialize_kernel(int kind, const T* __restrict__ X, int64_t ldx, int64
         stage_panel<T, DCV>(xs, X, L.n, ldx, nullptr, i0, c0, d, ell_vec);
         stage_panel<T, DCV>(ys, X, L.n, ldx, nullptr, j0, c0, d, ell_vec);
         __syncthreads();
-        tile_accumulate<T, L1>(xs, ys, ty, tx, acc, (int)((d - c0) < DCV ? (d - c0) : DCV));
+        tile_accumulate<T, L1, DCV>(xs, ys, ty, tx, acc, (int)((d - c0) < DCV ? (d - c0) : DCV));
     }
     T* base = Kp + L.row_offset(t) * W;
 #pragma unroll
