@@ -291,7 +291,8 @@ skinny_t_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
     constexpr int STEP = kWave * VW;
     constexpr int UNR = 8;
     const int lane = threadIdx.x & 63;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // wave index as a scalar: row addresses of V below become wave-uniform (scalar loads)
+    const int64_t wid = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wid >= nwork) return;
     const int64_t cc = wid % ncc;
     const int64_t seg = wid / ncc;
