@@ -281,8 +281,8 @@ static int sympack_materialize_impl(int kind, const T* X, int64_t n, int64_t ldx
 #define RK_SMAT(L1V, DCVV)                                                                        \
     hipLaunchKernelGGL((sympack_materialize_kernel<T, L1V, DCVV>), grid, dim3(256), 0, st, kind, X, \
                        ldx, d, w, ell_vec, (T)scale, L, Kp)
-    if (kind == RK_LAPLACE) { if (d <= 32) RK_SMAT(true, 32); else RK_SMAT(true, 64); }
-    else { if (d <= 32) RK_SMAT(false, 32); else RK_SMAT(false, 64); }
+    if (kind == RK_LAPLACE) RK_SMAT(true, 32);
+    else RK_SMAT(false, 32);
 #undef RK_SMAT
     return launch_status("rk_kernel_materialize_sympack");
 }

@@ -47,6 +47,22 @@ def main():
                     gb = (m * n + n * k + m * k) * es / 1e9
                     print(f"skinny {dt} m={m} n={n} k={k}: {med*1e3:.3f} ms  {gb/med:.0f} GB/s (best {gb/best:.0f})", flush=True)
                 del A
+    if "tall" in what:
+        for dt in (torch.float64, torch.float32):
+            es = 8 if dt == torch.float64 else 4
+            m, d = 2_000_000, 512
+            A = torch.randn(m, d, dtype=dt, device=dev)
+            x = torch.randn(d, 1, dtype=dt, device=dev)
+            u = torch.randn(m, 1, dtype=dt, device=dev)
+            med, _ = timeit(lambda: be.matmat(A, x))
+            print(f"tall A x {dt} {m}x{d}: {med*1e3:.3f} ms {m*d*es/med/1e9:.0f} GB/s", flush=True)
+            med, _ = timeit(lambda: be.rmatmat(A, u))
+            print(f"tall A^T u {dt} {m}x{d}: {med*1e3:.3f} ms {m*d*es/med/1e9:.0f} GB/s", flush=True)
+            med, _ = timeit(lambda: be.rmatmat(u, u, out_f64=True))
+            print(f"tall u^T u {dt} m={m}: {med*1e3:.3f} ms", flush=True)
+            med, _ = timeit(lambda: be.axpby_cols(u, None, u))
+            print(f"tall axpby {dt} m={m}: {med*1e3:.3f} ms", flush=True)
+            del A
     if "symm" in what:
         for dt in (torch.float32, torch.float64):
             es = 4 if dt == torch.float32 else 8
