@@ -169,6 +169,13 @@ int rk_pcg_update_wr(int dtype, int64_t n, int64_t k, void* W, int64_t ldw, void
 /* P = Z + P @ beta                            (rlaopt/solvers/pcg.py:82-83) */
 int rk_pcg_update_p(int dtype, int64_t n, int64_t k, void* P, int64_t ldp,
                     const void* Z, int64_t ldz, const double* beta, void* stream);
+/* G (k1 x k2, FLOAT64, row-major, device) = X^T Y for tall X (n x k1), Y (n x k2), k1, k2 <= 4,
+ * float64 accumulation, fixed-order two-stage reduction: the block inner products P^T AP,
+ * R^T Z (rlaopt/solvers/pcg.py:61,79) and the column norms of the residual metric
+ * (rlaopt/models/linsys.py:96-99) in two tiny launches. */
+size_t rk_gram_small_ws_bytes(int64_t n, int64_t k1, int64_t k2);
+int rk_gram_small(int dtype, const void* X, int64_t ldx, const void* Y, int64_t ldy, int64_t n,
+                  int64_t k1, int64_t k2, double* G, void* ws, size_t ws_bytes, void* stream);
 /* Y[:, c] = a[c] * X[:, c] + b[c] * Y[:, c]  (n x k, any k >= 1) with per-column
  * coefficients in device FLOAT64 arrays (a == NULL means 1, b == NULL means 0: Y is then
  * write-only).  The column-scaled updates of the LSQR recurrences, kept on the device so

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "librk_hip.so")
 
 RK_F32, RK_F64 = 0, 1
 KIND_IDS = {"rbf": 0, "laplace": 1, "matern12": 2, "matern32": 3, "matern52": 4}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # name -> (restype, argtypes); must list every symbol declared in include/rk.h
 SIGNATURES = {
@@ -78,6 +78,12 @@ SIGNATURES = {
     ),
     "rk_pcg_update_p": (
         c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]
+    ),
+    "rk_gram_small_ws_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
+    "rk_gram_small": (
+        c_int,
+        [c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+         c_size_t, c_void_p],
     ),
     "rk_axpby_cols": (
         c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]

@@ -429,6 +429,57 @@ pcg_update_p_kernel(int64_t n, int k, T* __restrict__ P, int64_t ldp, const T* _
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// G (k1 x k2, float64) = X^T Y for two tall row-major blocks with k1, k2 <= 4: the block inner
+// products of PCG (P^T AP, R^T Z), column norms, LSQR norms.  Stage 1: grid-stride over rows,
+// k1 k2 float64 accumulators per thread, wave total by DPP, 4 waves through LDS -> one partial
+// per workgroup; stage 2: one workgroup adds the partials in a fixed order.
+// ------------------------------------------------------------------------------------------
+template <typename T, int K1, int K2>
+__global__ void __launch_bounds__(256)
+gram_small_kernel(const T* __restrict__ X, int64_t ldx, const T* __restrict__ Y, int64_t ldy,
+                  int64_t n, double* __restrict__ part) {
+    __shared__ double red[4][K1 * K2];
+    double acc[K1][K2];
+#pragma unroll
+    for (int a = 0; a < K1; ++a)
+#pragma unroll
+        for (int b = 0; b < K2; ++b) acc[a][b] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        T x[K1], y[K2];
+#pragma unroll
+        for (int a = 0; a < K1; ++a) x[a] = X[i * ldx + a];
+#pragma unroll
+        for (int b = 0; b < K2; ++b) y[b] = Y[i * ldy + b];
+#pragma unroll
+        for (int a = 0; a < K1; ++a)
+#pragma unroll
+            for (int b = 0; b < K2; ++b) acc[a][b] += (double)x[a] * (double)y[b];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < K1; ++a)
+#pragma unroll
+        for (int b = 0; b < K2; ++b) {
+            const double tot = wave_total_lane63(acc[a][b]);
+            if (lane == 63) red[wave][a * K2 + b] = tot;
+        }
+    __syncthreads();
+    if (threadIdx.x < K1 * K2)
+        part[(int64_t)blockIdx.x * (K1 * K2) + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+__global__ void __launch_bounds__(64)
+gram_small_finish(const double* __restrict__ part, int nblocks, int kk, double* __restrict__ G) {
+    const int e = threadIdx.x;
+    if (e >= kk) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * kk + e];
+    G[e] = s;
+}
+
 // Y[:, c] = a[c] * X[:, c] + b[c] * Y[:, c] with device-resident float64 coefficients
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -802,6 +853,62 @@ extern "C" int rk_pcg_update_p(int dtype, int64_t n, int64_t k, void* P, int64_t
         hipLaunchKernelGGL((pcg_update_p_kernel<double>), grid, dim3(256), 0, st, n, (int)k,
                            (double*)P, ldp, (const double*)Z, ldz, beta);
     return launch_status("rk_pcg_update_p");
+}
+
+static int gram_small_blocks(int64_t n) {
+    int64_t b = ceil_div(n, 256 * 8);  // >= 8 rows per thread
+    if (b > 512) b = 512;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" size_t rk_gram_small_ws_bytes(int64_t n, int64_t k1, int64_t k2) {
+    if (n <= 0 || k1 < 1 || k2 < 1 || k1 > 4 || k2 > 4) return 0;
+    return (size_t)gram_small_blocks(n) * k1 * k2 * sizeof(double);
+}
+
+template <typename T>
+static int gram_small_dispatch(const T* X, int64_t ldx, const T* Y, int64_t ldy, int64_t n, int k1,
+                               int k2, double* part, int nb, hipStream_t st) {
+#define RK_GS(A, B)                                                                              \
+    case (A * 8 + B):                                                                            \
+        hipLaunchKernelGGL((gram_small_kernel<T, A, B>), dim3(nb), dim3(256), 0, st, X, ldx, Y,  \
+                           ldy, n, part);                                                        \
+        break;
+    switch (k1 * 8 + k2) {
+        RK_GS(1, 1) RK_GS(1, 2) RK_GS(1, 3) RK_GS(1, 4) RK_GS(2, 1) RK_GS(2, 2) RK_GS(2, 3)
+        RK_GS(2, 4) RK_GS(3, 1) RK_GS(3, 2) RK_GS(3, 3) RK_GS(3, 4) RK_GS(4, 1) RK_GS(4, 2)
+        RK_GS(4, 3) RK_GS(4, 4)
+        default: return RK_ERR_INVALID;
+    }
+#undef RK_GS
+    return launch_status("rk_gram_small");
+}
+
+extern "C" int rk_gram_small(int dtype, const void* X, int64_t ldx, const void* Y, int64_t ldy,
+                             int64_t n, int64_t k1, int64_t k2, double* G, void* ws,
+                             size_t ws_bytes, void* stream) {
+    clear_error();
+    RK_REQUIRE(dtype == RK_F32 || dtype == RK_F64, "rk_gram_small: bad dtype %d", dtype);
+    RK_REQUIRE(X && Y && G, "rk_gram_small: null pointer");
+    RK_REQUIRE(n > 0 && k1 >= 1 && k1 <= 4 && k2 >= 1 && k2 <= 4, "rk_gram_small: sizes outside [1,4]");
+    RK_REQUIRE(ldx >= k1 && ldy >= k2, "rk_gram_small: leading dimension too small");
+    const int nb = gram_small_blocks(n);
+    const size_t need = (size_t)nb * k1 * k2 * sizeof(double);
+    if (ws == nullptr || ws_bytes < need) {
+        set_error("rk_gram_small: workspace %zu B < required %zu B", ws_bytes, need);
+        return RK_ERR_WORKSPACE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double* part = static_cast<double*>(ws);
+    int rc = dtype == RK_F32
+                 ? gram_small_dispatch<float>((const float*)X, ldx, (const float*)Y, ldy, n, (int)k1,
+                                              (int)k2, part, nb, st)
+                 : gram_small_dispatch<double>((const double*)X, ldx, (const double*)Y, ldy, n,
+                                               (int)k1, (int)k2, part, nb, st);
+    if (rc != RK_OK) return rc;
+    hipLaunchKernelGGL(gram_small_finish, dim3(1), dim3(64), 0, st, part, nb, (int)(k1 * k2), G);
+    return launch_status("rk_gram_small(finish)");
 }
 
 extern "C" int rk_axpby_cols(int dtype, int64_t n, int64_t k, const void* X, int64_t ldx,

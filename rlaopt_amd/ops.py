@@ -290,7 +290,16 @@ class HipBackend:
             C2, ldc = _rowmajor(C2)
         odt = torch.float64 if out_f64 else A.dtype
         out = torch.empty((n, k), dtype=odt, device=dev)
-        if k <= MAX_SKINNY:
+        if out_f64 and n <= 4 and k <= 4 and beta == 0.0:
+            # block inner product of two tall blocks: dedicated two-launch reduction
+            ws, wsn = self._workspace(dev, self._lib.rk_gram_small_ws_bytes(m, n, k))
+            rc = self._lib.rk_gram_small(
+                _dt(A), _ptr(A), lda, _ptr(V2), ldv, m, n, k, _ptr(out), _ptr(ws), wsn, _stream(dev)
+            )
+            _lib.check(rc, "rk_gram_small")
+            if alpha != 1.0:
+                out.mul_(alpha)
+        elif k <= MAX_SKINNY:
             nbytes = self._lib.rk_matmat_skinny_t_ws_bytes(_dt(A), m, n, k)
             ws, wsn = self._workspace(dev, nbytes)
             rc = self._lib.rk_matmat_skinny_t(

@@ -244,3 +244,22 @@ def test_sympack_product_matches_dense(be, prec, kind, n, k):
     assert got1.ndim == 1 and rel_err(got1.cpu(), want[:, 0]) < LIM[dt] * 5
     # reproducible bit for bit
     assert torch.equal(be.symm_matmat(Kp, n, Vd), be.symm_matmat(Kp, n, Vd))
+
+
+@pytest.mark.parametrize("n", [1, 255, 4097, 300000])
+@pytest.mark.parametrize("k1,k2", [(1, 1), (2, 3), (4, 4), (3, 1)])
+def test_gram_small_block_inner_products(be, prec, n, k1, k2):
+    dt = DTYPES[prec]
+    gen = torch.Generator().manual_seed(n + k1)
+    X = torch.randn(n, k1, dtype=dt, generator=gen)
+    Y = torch.randn(n, k2, dtype=dt, generator=gen)
+    got = be.rmatmat(X.to(dev()), Y.to(dev()), out_f64=True)
+    assert got.dtype == torch.float64 and got.shape == (k1, k2)
+    want = X.double().T @ Y.double()
+    assert float((got.cpu() - want).abs().max()) <= 1e-12 * max(1.0, float(want.abs().max())) * n**0.5
+    assert torch.equal(got, be.rmatmat(X.to(dev()), Y.to(dev()), out_f64=True))  # reproducible
+    # strided views (columns of a wider array)
+    Z = torch.randn(n, 6, dtype=dt, generator=gen).to(dev())
+    got = be.rmatmat(Z[:, 1:3], Z[:, 2:5], out_f64=True)
+    want = Z[:, 1:3].double().T @ Z[:, 2:5].double()
+    assert float((got - want).abs().max()) <= 1e-12 * max(1.0, float(want.abs().max())) * n**0.5
