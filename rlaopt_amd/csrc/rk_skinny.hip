@@ -471,13 +471,15 @@ gram_small_kernel(const T* __restrict__ X, int64_t ldx, const T* __restrict__ Y,
             ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
+// one wave per output entry: lane l adds the partials l, l + 64, ... (independent loads in
+// flight), then one DPP wave total - fixed order, reproducible
 __global__ void __launch_bounds__(64)
 gram_small_finish(const double* __restrict__ part, int nblocks, int kk, double* __restrict__ G) {
-    const int e = threadIdx.x;
-    if (e >= kk) return;
+    const int e = blockIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * kk + e];
-    G[e] = s;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += part[(int64_t)b * kk + e];
+    s = wave_total_lane63(s);
+    if (threadIdx.x == 63) G[e] = s;
 }
 
 // Y[:, c] = a[c] * X[:, c] + b[c] * Y[:, c] with device-resident float64 coefficients
@@ -907,7 +909,8 @@ extern "C" int rk_gram_small(int dtype, const void* X, int64_t ldx, const void* 
                  : gram_small_dispatch<double>((const double*)X, ldx, (const double*)Y, ldy, n,
                                                (int)k1, (int)k2, part, nb, st);
     if (rc != RK_OK) return rc;
-    hipLaunchKernelGGL(gram_small_finish, dim3(1), dim3(64), 0, st, part, nb, (int)(k1 * k2), G);
+    hipLaunchKernelGGL(gram_small_finish, dim3((unsigned)(k1 * k2)), dim3(64), 0, st, part, nb,
+                       (int)(k1 * k2), G);
     return launch_status("rk_gram_small(finish)");
 }
 

@@ -63,7 +63,7 @@ def _same_points(A1: torch.Tensor, A2: torch.Tensor) -> bool:
     )
 
 
-_PANEL_BYTES = 4 << 30  # temporary row-major panel for wide products in sympack mode
+_PANEL_BYTES = 16 << 30  # temporary row-major panel for wide products in sympack mode (>= 512 GEMM tiles)
 _SYM_MAX_COLS = 16      # beyond this many columns a product goes through panels + MFMA
 
 
@@ -106,7 +106,10 @@ class _SymPackBlock:
         """Rows [lo, hi) of K x for many columns: temporary row-major panels + GEMM."""
         be = get_backend()
         es = x.element_size()
-        rpp = max(256, min(hi - lo, _PANEL_BYTES // (self.n * es)))
+        budget = _PANEL_BYTES
+        if x.is_cuda:
+            budget = min(budget, int(0.5 * torch.cuda.mem_get_info(x.device)[0]))
+        rpp = max(256, min(hi - lo, budget // (self.n * es)))
         if self._panel is None or self._panel.shape[0] < min(rpp, hi - lo):
             self._panel = torch.empty((min(rpp, hi - lo), self.n), dtype=x.dtype, device=x.device)
         out = torch.empty((hi - lo, x.shape[1]), dtype=x.dtype, device=x.device)
