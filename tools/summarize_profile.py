@@ -27,7 +27,7 @@ rows = list(csv.DictReader(open(stats)))
 
 bench = json.loads([l for l in open(f"{src}/{tag}_bench_n1.log") if l.startswith("{")][-1])
 storage = bench["roofline"].get("storage", "materialize")
-KNAME = "symm_strip_kernel" if storage == "sympack" else "skinny_nn_kernel"
+KNAME = "symm_strip_kernel<float, 1>" if storage == "sympack" else "skinny_nn_kernel<float, 1, 8"
 
 
 def pmc(kind):
