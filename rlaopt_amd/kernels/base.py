@@ -32,7 +32,7 @@ import torch
 
 from .. import dist as _dist
 from ..linops import LinOp, ScaleMixin, TwoSidedLinOp
-from ..linops.base import _BaseLinOp, _RemoteShard
+from ..linops.base import _RemoteShard
 from ..linops.distributed import _DistributedLinOp, _DistributedTwoSidedLinOp
 from ..ops import get_backend
 from ..utils import _is_set, _is_torch_tensor

@@ -13,7 +13,6 @@ package ever does so by itself.
 from __future__ import annotations
 
 import contextlib
-import math
 
 import torch
 
@@ -443,7 +442,3 @@ def use_backend(backend):
         yield backend
     finally:
         _backend = prev
-
-
-def sqrt_int(x):  # tiny helper shared by the sketches
-    return math.sqrt(float(x))

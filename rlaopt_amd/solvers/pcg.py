@@ -25,7 +25,6 @@ from typing import TYPE_CHECKING
 
 import torch
 
-from .. import dist as _dist
 from ..ops import get_backend
 from ..preconditioners import PreconditionerConfig
 from ..preconditioners import _get_precond as _pf_get_precond

@@ -244,6 +244,11 @@ def test_sympack_product_matches_dense(be, prec, kind, n, k):
     assert got1.ndim == 1 and rel_err(got1.cpu(), want[:, 0]) < LIM[dt] * 5
     # reproducible bit for bit
     assert torch.equal(be.symm_matmat(Kp, n, Vd), be.symm_matmat(Kp, n, Vd))
+    # per-feature (ARD) lengthscale
+    ard = (torch.rand(d, dtype=dt, generator=gen) + 0.5)
+    Kp = be.sympack_materialize(kind, Xd, ard.to(dev()), scale=1.0)
+    want = ok.kernel_matrix(kind, X.double(), X.double(), ard.double(), 1.0) @ V.double()
+    assert rel_err(be.symm_matmat(Kp, n, Vd).cpu(), want) < LIM[dt] * 5
 
 
 @pytest.mark.parametrize("n", [1, 255, 4097, 300000])

@@ -11,7 +11,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from rlaopt_amd.kernels import DistributedRBFLinOp, KernelConfig, RBFLinOp
+from rlaopt_amd.kernels import DistributedRBFLinOp, KernelConfig
 from rlaopt_amd.models import LinSys
 from rlaopt_amd.preconditioners import NystromConfig
 from rlaopt_amd.solvers import SAPAccelConfig, SAPConfig
