@@ -42,14 +42,14 @@ import torch.distributed as td  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 is the measured copy ceiling
 
 
-def make_problem(n, d, r, seed_x=0, seed_om=1):
+def make_problem(n, d, r, dt, seed_x=0, seed_om=1):
     g = torch.Generator().manual_seed(seed_x)
-    X = (torch.randn(n, d, dtype=torch.float64, generator=g) / d**0.5).float()
-    B = torch.randn(n, 1, dtype=torch.float64, generator=g).float()
+    X = (torch.randn(n, d, dtype=torch.float64, generator=g) / d**0.5).to(dt)
+    B = torch.randn(n, 1, dtype=torch.float64, generator=g).to(dt)
     g = torch.Generator().manual_seed(seed_om)
-    Om = torch.empty(n, r, dtype=torch.float32)
+    Om = torch.empty(n, r, dtype=dt)
     for c0 in range(0, r, 64):  # randn(r, n)/sqrt(r) transposed, drawn in slabs to bound memory
-        Om[:, c0 : c0 + 64] = (torch.randn(min(64, r - c0), n, dtype=torch.float64, generator=g) / r**0.5).T.float()
+        Om[:, c0 : c0 + 64] = (torch.randn(min(64, r - c0), n, dtype=torch.float64, generator=g) / r**0.5).T.to(dt)
     return X, B, Om
 
 
@@ -60,7 +60,7 @@ def cpu_baseline(X, n, budget_s=12.0):
     from oracle import cbind
 
     cores = cbind.num_threads()
-    V = torch.ones(n, 1, dtype=torch.float32)
+    V = torch.ones(n, 1, dtype=X.dtype)
     rows, spent, done_rows = 256, 0.0, 0
     cbind.kernel_matmat("rbf", X[:64], X, 1.0, V)  # warm the threads
     while spent < budget_s and rows <= n:
@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--d", type=int, default=64)
     ap.add_argument("--rank", type=int, default=512)
     ap.add_argument("--callback-freq", type=int, default=10)
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32",
+                    help="f32 is the BASELINE.json configuration; f64 is the secondary run of SURVEY 8(d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solve", action="store_true", help="skip the full solve to tolerance")
     args = ap.parse_args()
@@ -144,7 +146,9 @@ def main():
     be = get_backend()
     n, d, r, k = args.n, args.d, args.rank, 1
     reg = 1e-6 * n
-    X, B, Om = make_problem(n, d, r)
+    dt = torch.float32 if args.dtype == "f32" else torch.float64
+    es = 4 if args.dtype == "f32" else 8
+    X, B, Om = make_problem(n, d, r, dt)
     Xd, Bd, Omd = X.to(dev), B.to(dev), Om.to(dev)
 
     def sync():
@@ -158,13 +162,13 @@ def main():
     A = DistributedRBFLinOp(Xd, Xd, KernelConfig(lengthscale=1.0), devices={dev})
     system = LinSys(A, Bd, reg=reg)
     lo, hi = A.row_range if A.is_row_sharded else (0, n)
-    _ = A.local_matmat(torch.zeros(n, 1, device=dev))  # forces materialisation
+    _ = A.local_matmat(torch.zeros(n, 1, dtype=dt, device=dev))  # forces materialisation
     sync()
     t_mat = time.time() - t0
     t0 = time.time()
     pcfg = NystromConfig(rank=r, rho=reg, sketch="gauss", damping_mode="adaptive")
     with sketches.inject(Omd):
-        solver = PCG(system, torch.zeros(n, k, device=dev), pcfg, dev)
+        solver = PCG(system, torch.zeros(n, k, dtype=dt, device=dev), pcfg, dev)
     system._active_solver = solver  # what LinSys.solve does: metric and next step share a pass
     sync()
     t_pre = time.time() - t0
@@ -209,7 +213,7 @@ def main():
     if rank == 0:
         rows8 = n // 8
         Ksh = be.kernel_materialize("rbf", Xd[:rows8], Xd, 1.0)
-        vv = torch.randn(n, 1, device=dev)
+        vv = torch.randn(n, 1, dtype=dt, device=dev)
         be.matmat(Ksh, vv)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -219,8 +223,8 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
-        nbytes = (rows8 * n + n + rows8) * 4
-        rowmajor = {"kernel": "rk_matmat_skinny (skinny_nn_kernel<float,1,8>)", "shard": f"{rows8} x {n} fp32 (the p = 8 shard)",
+        nbytes = (rows8 * n + n + rows8) * es
+        rowmajor = {"kernel": "rk_matmat_skinny (skinny_nn_kernel<T,1,8>)", "shard": f"{rows8} x {n} {args.dtype} (the p = 8 shard)",
                     "avg_launch_ms": ms, "achieved_GBps": nbytes / (ms * 1e-3) / 1e9,
                     "frac_of_8000": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         del Ksh, vv
@@ -237,7 +241,7 @@ def main():
         sync()
         t0 = time.time()
         with sketches.inject(Omd):
-            W, log = system2.solve(cfg, torch.zeros(n, k, device=dev), callback_freq=args.callback_freq)
+            W, log = system2.solve(cfg, torch.zeros(n, k, dtype=dt, device=dev), callback_freq=args.callback_freq)
         sync()
         solve = {
             "solve_iters": max(log),
@@ -258,7 +262,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {
                 "workload": f"rbf_krr_pcg n={n} d={d} k={k} nystrom_rank={r} reg=1e-6*n "
@@ -279,13 +283,13 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": committed_traffic(world, n, mode),
+                "traffic": committed_traffic(world, n, mode) if args.dtype == "f32" else None,
                 "bytes_per_launch": mv["bytes_per_launch"],
                 "avg_launch_ms": mv["avg_ms"],
                 "launches": mv["launches"],
             },
             "matvec_GBps_aggregate": achieved * world,
-            "matvec_dense_equivalent_GBps_aggregate": (n * n * 4.0 / (mv["avg_ms"] * 1e-3) / 1e9) if mv["launches"] else None,
+            "matvec_dense_equivalent_GBps_aggregate": (n * n * float(es) / (mv["avg_ms"] * 1e-3) / 1e9) if mv["launches"] else None,
             "rowmajor_shard_product": rowmajor,
             "setup_materialize_s": round(t_mat, 3),
             "setup_nystrom_s": round(t_pre, 3),
@@ -294,7 +298,7 @@ def main():
             **solve,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(X, n)
+            out["cpu_baseline"] = cpu_baseline(X, n)  # same dtype as the GPU run
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
