@@ -113,10 +113,14 @@ def main():
     ap.add_argument("--callback-freq", type=int, default=10)
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32",
                     help="f32 is the BASELINE.json configuration; f64 is the secondary run of SURVEY 8(d)")
+    ap.add_argument("--storage", choices=["same", "f32"], default="same",
+                    help="with --dtype f64: keep the packed kernel matrix in float32 (RK_STORAGE_DTYPE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solve", action="store_true", help="skip the full solve to tolerance")
     args = ap.parse_args()
 
+    if args.storage == "f32":
+        os.environ["RK_STORAGE_DTYPE"] = "float32"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -272,9 +276,9 @@ def main():
                 "parallelism": f"row-shard x{world}",
             },
             "roofline": {
-                "kernel": ("rk_symm_matmat (symm_strip_kernel<float,1>): strip-packed upper triangle, every "
+                "kernel": ("rk_symm_matmat (symm_strip_kernel): strip-packed upper triangle, every "
                            "stored entry used for y[i] and y[j]; algorithmic bytes = packed triangle + V + Y"
-                           if mode == "sympack" else
+                           if mode.startswith("sympack") else
                            "rk_matmat_skinny (skinny_nn_kernel<float,1,8>): row-major shard; algorithmic "
                            "bytes = (n_loc n + n k + n_loc k) * 4"),
                 "storage": mode,

@@ -92,16 +92,22 @@ int rk_kernel_matmat(int dtype, int kind,
  * is this rank's PARTIAL sum over its strips (complete when strip_stride == 1); partials of
  * different ranks add up to K V (all-reduce).  1 <= k <= 4 per call.  No reference
  * counterpart: the reference never exploits A1 is A2 (rlaopt/kernels/base.py:23-128). */
-size_t rk_sympack_elems(int dtype, int64_t n, int64_t strip_first, int64_t strip_stride);
-int rk_kernel_materialize_sympack(int dtype, int kind, const void* X, int64_t n, int64_t ldx,
-                                  int64_t d, double ell_scalar, const void* ell_vec, double scale,
-                                  int64_t strip_first, int64_t strip_stride, void* Kp, void* stream);
-size_t rk_symm_matmat_ws_bytes(int dtype, int64_t n, int64_t k, int64_t strip_first,
-                               int64_t strip_stride);
+/* `store_dtype` is the element type of the packed matrix: equal to `dtype`, or RK_F32 under
+ * RK_F64 arithmetic ("fp32 storage, fp64 iteration": entries are computed in float64 and
+ * rounded once; products convert them back and accumulate in float64 - fp32 HBM traffic with
+ * float64 vectors, so a Krylov solve is not limited by fp32 round-off in its recurrences). */
+size_t rk_sympack_elems(int store_dtype, int64_t n, int64_t strip_first, int64_t strip_stride);
+int rk_kernel_materialize_sympack(int dtype, int store_dtype, int kind, const void* X, int64_t n,
+                                  int64_t ldx, int64_t d, double ell_scalar, const void* ell_vec,
+                                  double scale, int64_t strip_first, int64_t strip_stride,
+                                  void* Kp, void* stream);
+size_t rk_symm_matmat_ws_bytes(int dtype, int store_dtype, int64_t n, int64_t k,
+                               int64_t strip_first, int64_t strip_stride);
 /* Y (n x k) = alpha * (partial) K V + diag_shift * V */
-int rk_symm_matmat(int dtype, const void* Kp, int64_t n, int64_t strip_first, int64_t strip_stride,
-                   const void* V, int64_t k, int64_t ldv, double alpha, double diag_shift,
-                   void* Y, int64_t ldy, void* ws, size_t ws_bytes, void* stream);
+int rk_symm_matmat(int dtype, int store_dtype, const void* Kp, int64_t n, int64_t strip_first,
+                   int64_t strip_stride, const void* V, int64_t k, int64_t ldv, double alpha,
+                   double diag_shift, void* Y, int64_t ldy, void* ws, size_t ws_bytes,
+                   void* stream);
 
 /* ------------------------------------------------------------------------------------
  * HBM-streaming skinny products  [a3 cached shard product, a6 dense tensor operator,

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "librk_hip.so")
 
 RK_F32, RK_F64 = 0, 1
 KIND_IDS = {"rbf": 0, "laplace": 1, "matern12": 2, "matern32": 3, "matern52": 4}
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # name -> (restype, argtypes); must list every symbol declared in include/rk.h
 SIGNATURES = {
@@ -37,14 +37,14 @@ SIGNATURES = {
     "rk_sympack_elems": (c_size_t, [c_int, c_int64, c_int64, c_int64]),
     "rk_kernel_materialize_sympack": (
         c_int,
-        [c_int, c_int, c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_double, c_int64,
-         c_int64, c_void_p, c_void_p],
+        [c_int, c_int, c_int, c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_double,
+         c_int64, c_int64, c_void_p, c_void_p],
     ),
-    "rk_symm_matmat_ws_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64, c_int64]),
+    "rk_symm_matmat_ws_bytes": (c_size_t, [c_int, c_int, c_int64, c_int64, c_int64, c_int64]),
     "rk_symm_matmat": (
         c_int,
-        [c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_double, c_double,
-         c_void_p, c_int64, c_void_p, c_size_t, c_void_p],
+        [c_int, c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_double,
+         c_double, c_void_p, c_int64, c_void_p, c_size_t, c_void_p],
     ),
     "rk_matmat_skinny_ws_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64]),
     "rk_matmat_skinny": (

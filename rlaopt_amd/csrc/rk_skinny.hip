@@ -693,8 +693,8 @@ static TPlan plan_t(int dtype, int64_t m, int64_t n) {
     const int64_t step = (dtype == RK_F32) ? 256 : 128;
     TPlan p;
     p.ncc = ceil_div(n, step);
-    int64_t S = ceil_div(32768, p.ncc);  // ~32k waves
-    const int64_t max_S = ceil_div(m, 128);  // >= 128 rows per wave
+    int64_t S = ceil_div(16384, p.ncc);  // ~16k waves (4 rounds of the resident set)
+    const int64_t max_S = ceil_div(m, 256);  // >= 256 rows per wave
     if (S > max_S) S = max_S;
     if (S < 1) S = 1;
     p.seg_rows = ceil_div(m, S);

@@ -55,12 +55,12 @@ constexpr int ITEM_ROWS = 1024;  // rows of a strip handled by one workgroup (4 
 // ------------------------------------------------------------------------------------------
 // materialise the packed triangle
 // ------------------------------------------------------------------------------------------
-template <typename T, bool L1, int DCV>
+template <typename T, typename TS, bool L1, int DCV>
 __global__ void __launch_bounds__(256)
 sympack_materialize_kernel(int kind, const T* __restrict__ X, int64_t ldx, int64_t d, T w,
                            const T* __restrict__ ell_vec, T scale, SymLayout L,
-                           T* __restrict__ Kp) {
-    constexpr int W = strip_width<T>();
+                           TS* __restrict__ Kp) {
+    constexpr int W = strip_width<TS>();
     constexpr int CT = W / TN;  // column tiles per strip
     __shared__ T xs[DCV][LDP];
     __shared__ T ys[DCV][LDP];
@@ -83,19 +83,19 @@ sympack_materialize_kernel(int kind, const T* __restrict__ X, int64_t ldx, int64
         __syncthreads();
         tile_accumulate<T, L1, DCV>(xs, ys, ty, tx, acc, (int)((d - c0) < DCV ? (d - c0) : DCV));
     }
-    T* base = Kp + L.row_offset(t) * W;
+    TS* base = Kp + L.row_offset(t) * W;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t i = i0 + ty * 4 + r;
         if (i >= nrows) continue;
-        T o[4];
+        TS o[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int64_t j = j0 + tx * 4 + q;
-            o[q] = (j < L.n) ? scale * kernel_value<T>(kind, acc[r][q], w) : T(0);
+            o[q] = (j < L.n) ? (TS)(scale * kernel_value<T>(kind, acc[r][q], w)) : TS(0);
         }
-        T* dst = base + i * W + jt * TN + tx * 4;
-        if constexpr (sizeof(T) == 4) {
+        TS* dst = base + i * W + jt * TN + tx * 4;
+        if constexpr (sizeof(TS) == 4) {
             *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
         } else {
             *reinterpret_cast<double2*>(dst) = make_double2(o[0], o[1]);
@@ -107,13 +107,15 @@ sympack_materialize_kernel(int kind, const T* __restrict__ X, int64_t ldx, int64
 // ------------------------------------------------------------------------------------------
 // the strip product
 // ------------------------------------------------------------------------------------------
-template <typename T, int K>
+// TS = storage type of the packed matrix, T = type of the vectors and of all arithmetic
+// (TS = float with T = double: "fp32 storage, fp64 iteration" - fp32 HBM traffic, fp64 accuracy)
+template <typename TS, typename T, int K>
 __global__ void __launch_bounds__(256)
-symm_strip_kernel(const T* __restrict__ Kp, SymLayout L, const T* __restrict__ V, int64_t ldv,
+symm_strip_kernel(const TS* __restrict__ Kp, SymLayout L, const T* __restrict__ V, int64_t ldv,
                   T* __restrict__ Prow, T* __restrict__ Pcol, int64_t max_items) {
-    using V16 = typename Vec16<T>::type;
-    constexpr int VW = Vec16<T>::N;
-    constexpr int W = strip_width<T>();
+    using V16 = typename Vec16<TS>::type;
+    constexpr int VW = Vec16<TS>::N;
+    constexpr int W = strip_width<TS>();
     constexpr int RB = 8;                     // rows per batch (loads in flight per stage)
     constexpr int WAVE_ROWS = ITEM_ROWS / 4;  // 256
     __shared__ T rowbuf[4][WAVE_ROWS][K];
@@ -127,7 +129,7 @@ symm_strip_kernel(const T* __restrict__ Kp, SymLayout L, const T* __restrict__ V
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t s = L.strip(t);
     const int64_t diag_lo = s * W;  // rows >= diag_lo belong to the (fully stored) diagonal block
-    const T* base = Kp + L.row_offset(t) * W;
+    const TS* base = Kp + L.row_offset(t) * W;
     const int64_t r_lo = item_lo + (int64_t)wave * WAVE_ROWS;
     int64_t r_hi = r_lo + WAVE_ROWS;
     if (r_hi > nrows) r_hi = nrows;
@@ -165,7 +167,10 @@ symm_strip_kernel(const T* __restrict__ Kp, SymLayout L, const T* __restrict__ V
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const bool live = i0 + r < r_hi;
-            const T* ae = reinterpret_cast<const T*>(&cur[r]);
+            const TS* as = reinterpret_cast<const TS*>(&cur[r]);
+            T ae[VW];
+#pragma unroll
+            for (int q = 0; q < VW; ++q) ae[q] = (T)as[q];
             T dot[K];
 #pragma unroll
             for (int c = 0; c < K; ++c) dot[c] = T(0);
@@ -267,19 +272,19 @@ static SymLayout make_layout(int64_t n, int64_t first, int64_t stride) {
     return L;
 }
 
-template <typename T>
+template <typename T, typename TS>
 static int sympack_materialize_impl(int kind, const T* X, int64_t n, int64_t ldx, int64_t d,
                                     double ell, const T* ell_vec, double scale, int64_t first,
-                                    int64_t stride, T* Kp, hipStream_t st) {
-    const SymLayout L = make_layout<T>(n, first, stride);
+                                    int64_t stride, TS* Kp, hipStream_t st) {
+    const SymLayout L = make_layout<TS>(n, first, stride);
     const int64_t T_loc = L.strips_local();
     if (T_loc == 0) return RK_OK;
-    constexpr int CT = strip_width<T>() / TN;
+    constexpr int CT = strip_width<TS>() / TN;
     const int64_t max_rows = L.rows(T_loc - 1);
     dim3 grid((unsigned)(ceil_div(max_rows, TM) * CT), (unsigned)T_loc);
     const T w = ell_vec ? T(1) : T(1.0 / ell);
 #define RK_SMAT(L1V, DCVV)                                                                        \
-    hipLaunchKernelGGL((sympack_materialize_kernel<T, L1V, DCVV>), grid, dim3(256), 0, st, kind, X, \
+    hipLaunchKernelGGL((sympack_materialize_kernel<T, TS, L1V, DCVV>), grid, dim3(256), 0, st, kind, X, \
                        ldx, d, w, ell_vec, (T)scale, L, Kp)
     if (kind == RK_LAPLACE) RK_SMAT(true, 32);
     else RK_SMAT(false, 32);
@@ -287,23 +292,23 @@ static int sympack_materialize_impl(int kind, const T* X, int64_t n, int64_t ldx
     return launch_status("rk_kernel_materialize_sympack");
 }
 
-template <typename T>
+template <typename TS, typename T>
 static size_t symm_ws_bytes(int64_t n, int64_t k, int64_t first, int64_t stride) {
-    const SymLayout L = make_layout<T>(n, first, stride);
+    const SymLayout L = make_layout<TS>(n, first, stride);
     const int64_t max_items = ceil_div(n, ITEM_ROWS);
     const size_t prow = (size_t)L.total_rows() * k;
     const size_t pcol = (size_t)L.strips_local() * max_items * L.W * k;
     return (prow + pcol) * sizeof(T);
 }
 
-template <typename T>
-static int symm_matmat_impl(const T* Kp, int64_t n, int64_t first, int64_t stride, const T* V,
+template <typename TS, typename T>
+static int symm_matmat_impl(const TS* Kp, int64_t n, int64_t first, int64_t stride, const T* V,
                             int64_t k, int64_t ldv, double alpha, double shift, T* Y, int64_t ldy,
                             void* ws, size_t ws_bytes, hipStream_t st) {
-    const SymLayout L = make_layout<T>(n, first, stride);
+    const SymLayout L = make_layout<TS>(n, first, stride);
     const int64_t T_loc = L.strips_local();
     const int64_t max_items = ceil_div(n, ITEM_ROWS);
-    const size_t need = symm_ws_bytes<T>(n, k, first, stride);
+    const size_t need = symm_ws_bytes<TS, T>(n, k, first, stride);
     if (need > 0 && (ws == nullptr || ws_bytes < need)) {
         set_error("rk_symm_matmat: workspace %zu B < required %zu B", ws_bytes, need);
         return RK_ERR_WORKSPACE;
@@ -313,7 +318,7 @@ static int symm_matmat_impl(const T* Kp, int64_t n, int64_t first, int64_t strid
     if (T_loc > 0) {
         dim3 grid((unsigned)ceil_div(L.rows(T_loc - 1), ITEM_ROWS), (unsigned)T_loc);
 #define RK_SYMM(KK)                                                                             \
-    hipLaunchKernelGGL((symm_strip_kernel<T, KK>), grid, dim3(256), 0, st, Kp, L, V, ldv, Prow,  \
+    hipLaunchKernelGGL((symm_strip_kernel<TS, T, KK>), grid, dim3(256), 0, st, Kp, L, V, ldv, Prow, \
                        Pcol, max_items)
         switch (k) {
             case 1: RK_SYMM(1); break;
@@ -334,26 +339,31 @@ static int symm_matmat_impl(const T* Kp, int64_t n, int64_t first, int64_t strid
 
 using namespace rk;
 
-static int check_layout(const char* fn, int dtype, int64_t n, int64_t first, int64_t stride) {
+static int check_layout(const char* fn, int dtype, int store_dtype, int64_t n, int64_t first,
+                        int64_t stride) {
     RK_REQUIRE(dtype == RK_F32 || dtype == RK_F64, "%s: bad dtype %d", fn, dtype);
+    RK_REQUIRE(store_dtype == dtype || (dtype == RK_F64 && store_dtype == RK_F32),
+               "%s: storage dtype must equal dtype, or be float32 under float64 arithmetic", fn);
     RK_REQUIRE(n > 0, "%s: n must be positive", fn);
     RK_REQUIRE(stride >= 1 && first >= 0 && first < stride, "%s: need 0 <= strip_first < strip_stride", fn);
     return RK_OK;
 }
 
-extern "C" size_t rk_sympack_elems(int dtype, int64_t n, int64_t strip_first, int64_t strip_stride) {
+extern "C" size_t rk_sympack_elems(int store_dtype, int64_t n, int64_t strip_first,
+                                   int64_t strip_stride) {
     if (n <= 0 || strip_stride < 1 || strip_first < 0 || strip_first >= strip_stride) return 0;
-    const SymLayout L = dtype == RK_F32 ? make_layout<float>(n, strip_first, strip_stride)
-                                        : make_layout<double>(n, strip_first, strip_stride);
+    const SymLayout L = store_dtype == RK_F32 ? make_layout<float>(n, strip_first, strip_stride)
+                                              : make_layout<double>(n, strip_first, strip_stride);
     return (size_t)L.total_rows() * L.W;
 }
 
-extern "C" int rk_kernel_materialize_sympack(int dtype, int kind, const void* X, int64_t n,
-                                             int64_t ldx, int64_t d, double ell_scalar,
+extern "C" int rk_kernel_materialize_sympack(int dtype, int store_dtype, int kind, const void* X,
+                                             int64_t n, int64_t ldx, int64_t d, double ell_scalar,
                                              const void* ell_vec, double scale, int64_t strip_first,
                                              int64_t strip_stride, void* Kp, void* stream) {
     clear_error();
-    int rc = check_layout("rk_kernel_materialize_sympack", dtype, n, strip_first, strip_stride);
+    int rc = check_layout("rk_kernel_materialize_sympack", dtype, store_dtype, n, strip_first,
+                          strip_stride);
     if (rc != RK_OK) return rc;
     RK_REQUIRE(kind >= RK_RBF && kind <= RK_MATERN52, "rk_kernel_materialize_sympack: bad kind %d", kind);
     RK_REQUIRE(X && Kp, "rk_kernel_materialize_sympack: null pointer");
@@ -362,28 +372,33 @@ extern "C" int rk_kernel_materialize_sympack(int dtype, int kind, const void* X,
     RK_REQUIRE(aligned16(Kp), "rk_kernel_materialize_sympack: output must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == RK_F32)
-        return sympack_materialize_impl<float>(kind, (const float*)X, n, ldx, d, ell_scalar,
-                                               (const float*)ell_vec, scale, strip_first,
-                                               strip_stride, (float*)Kp, st);
-    return sympack_materialize_impl<double>(kind, (const double*)X, n, ldx, d, ell_scalar,
-                                            (const double*)ell_vec, scale, strip_first, strip_stride,
-                                            (double*)Kp, st);
+        return sympack_materialize_impl<float, float>(kind, (const float*)X, n, ldx, d, ell_scalar,
+                                                      (const float*)ell_vec, scale, strip_first,
+                                                      strip_stride, (float*)Kp, st);
+    if (store_dtype == RK_F32)
+        return sympack_materialize_impl<double, float>(kind, (const double*)X, n, ldx, d, ell_scalar,
+                                                       (const double*)ell_vec, scale, strip_first,
+                                                       strip_stride, (float*)Kp, st);
+    return sympack_materialize_impl<double, double>(kind, (const double*)X, n, ldx, d, ell_scalar,
+                                                    (const double*)ell_vec, scale, strip_first,
+                                                    strip_stride, (double*)Kp, st);
 }
 
-extern "C" size_t rk_symm_matmat_ws_bytes(int dtype, int64_t n, int64_t k, int64_t strip_first,
-                                          int64_t strip_stride) {
+extern "C" size_t rk_symm_matmat_ws_bytes(int dtype, int store_dtype, int64_t n, int64_t k,
+                                          int64_t strip_first, int64_t strip_stride) {
     if (n <= 0 || k < 1 || k > 4 || strip_stride < 1 || strip_first < 0 || strip_first >= strip_stride)
         return 0;
-    return dtype == RK_F32 ? symm_ws_bytes<float>(n, k, strip_first, strip_stride)
-                           : symm_ws_bytes<double>(n, k, strip_first, strip_stride);
+    if (dtype == RK_F32) return symm_ws_bytes<float, float>(n, k, strip_first, strip_stride);
+    return store_dtype == RK_F32 ? symm_ws_bytes<float, double>(n, k, strip_first, strip_stride)
+                                 : symm_ws_bytes<double, double>(n, k, strip_first, strip_stride);
 }
 
-extern "C" int rk_symm_matmat(int dtype, const void* Kp, int64_t n, int64_t strip_first,
-                              int64_t strip_stride, const void* V, int64_t k, int64_t ldv,
-                              double alpha, double diag_shift, void* Y, int64_t ldy, void* ws,
-                              size_t ws_bytes, void* stream) {
+extern "C" int rk_symm_matmat(int dtype, int store_dtype, const void* Kp, int64_t n,
+                              int64_t strip_first, int64_t strip_stride, const void* V, int64_t k,
+                              int64_t ldv, double alpha, double diag_shift, void* Y, int64_t ldy,
+                              void* ws, size_t ws_bytes, void* stream) {
     clear_error();
-    int rc = check_layout("rk_symm_matmat", dtype, n, strip_first, strip_stride);
+    int rc = check_layout("rk_symm_matmat", dtype, store_dtype, n, strip_first, strip_stride);
     if (rc != RK_OK) return rc;
     RK_REQUIRE(Kp && V && Y, "rk_symm_matmat: null pointer");
     RK_REQUIRE(k >= 1 && k <= 4, "rk_symm_matmat: k=%lld outside [1,4]", (long long)k);
@@ -391,8 +406,14 @@ extern "C" int rk_symm_matmat(int dtype, const void* Kp, int64_t n, int64_t stri
     RK_REQUIRE(aligned16(Kp), "rk_symm_matmat: packed matrix must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == RK_F32)
-        return symm_matmat_impl<float>((const float*)Kp, n, strip_first, strip_stride, (const float*)V,
-                                       k, ldv, alpha, diag_shift, (float*)Y, ldy, ws, ws_bytes, st);
-    return symm_matmat_impl<double>((const double*)Kp, n, strip_first, strip_stride, (const double*)V,
-                                    k, ldv, alpha, diag_shift, (double*)Y, ldy, ws, ws_bytes, st);
+        return symm_matmat_impl<float, float>((const float*)Kp, n, strip_first, strip_stride,
+                                              (const float*)V, k, ldv, alpha, diag_shift, (float*)Y,
+                                              ldy, ws, ws_bytes, st);
+    if (store_dtype == RK_F32)
+        return symm_matmat_impl<float, double>((const float*)Kp, n, strip_first, strip_stride,
+                                               (const double*)V, k, ldv, alpha, diag_shift, (double*)Y,
+                                               ldy, ws, ws_bytes, st);
+    return symm_matmat_impl<double, double>((const double*)Kp, n, strip_first, strip_stride,
+                                            (const double*)V, k, ldv, alpha, diag_shift, (double*)Y, ldy,
+                                            ws, ws_bytes, st);
 }

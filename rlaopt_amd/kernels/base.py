@@ -21,6 +21,13 @@ symmetric packed ("sympack", default when A1 is A2 and the triangle fits)
     sketch) go through temporary row-major panels and the matrix cores.
 
 ``RK_KERNEL_MODE`` = "auto" | "sympack" | "materialize" | "matrix_free" overrides the choice.
+
+``RK_STORAGE_DTYPE=float32`` (sympack mode, float64 data): keep the packed entries in float32
+while every vector and every accumulation stays float64 - the product streams fp32 bytes, and
+the Krylov recurrences keep float64 accuracy.  The operator is then K rounded entry-wise to
+float32 (relative perturbation 6e-8); a pure float32 solve of the n = 200 000 benchmark system
+stagnates near 2e-4 relative residual (eps_32 x condition number), this mode reaches 1e-6 at
+the float32 iteration cost.  Off by default: results then match the reference dtype for dtype.
 """
 
 from __future__ import annotations
@@ -46,6 +53,15 @@ def _mode_override() -> str:
     if mode not in ("auto", "sympack", "materialize", "matrix_free"):
         raise ValueError(f"RK_KERNEL_MODE={mode!r}: expected auto|sympack|materialize|matrix_free")
     return mode
+
+
+def _storage_dtype(dtype: torch.dtype) -> torch.dtype:
+    want = os.environ.get("RK_STORAGE_DTYPE", "").lower()
+    if want in ("", "same"):
+        return dtype
+    if want in ("float32", "f32"):
+        return torch.float32 if dtype == torch.float64 else dtype
+    raise ValueError(f"RK_STORAGE_DTYPE={want!r}: expected float32 or unset")
 
 
 def _fits_in_hbm(rows: int, cols: int, dtype: torch.dtype, device: torch.device) -> bool:
@@ -74,12 +90,14 @@ class _SymPackBlock:
         self.kind, self.X, self.config = kind, X, config
         self.n, self.first, self.stride = X.shape[0], first, stride
         self.scale = float(getattr(config, "const_scaling", 1.0))
+        self.store_dtype = _storage_dtype(X.dtype)
         self._Kp = None
         self._panel = None
+        self._X_store = None
 
     @staticmethod
     def fits(n: int, stride: int, dtype, device) -> bool:
-        es = torch.empty((), dtype=dtype).element_size()
+        es = torch.empty((), dtype=_storage_dtype(dtype)).element_size()
         need = n * n * es // (2 * stride) + _PANEL_BYTES
         if device.type != "cuda":
             return True
@@ -91,7 +109,7 @@ class _SymPackBlock:
         if self._Kp is None:
             self._Kp = get_backend().sympack_materialize(
                 self.kind, self.X, self.config.lengthscale, scale=self.scale,
-                first=self.first, stride=self.stride,
+                first=self.first, stride=self.stride, store_dtype=self.store_dtype,
             )
         return self._Kp
 
@@ -103,8 +121,18 @@ class _SymPackBlock:
         )
 
     def rows_matmat_wide(self, x, lo: int, hi: int):
-        """Rows [lo, hi) of K x for many columns: temporary row-major panels + GEMM."""
+        """Rows [lo, hi) of K x for many columns: temporary row-major panels + GEMM (in the
+        storage dtype: with float32 storage the sketch product runs on the fp32 matrix cores)."""
         be = get_backend()
+        out_dtype = x.dtype
+        X = self.X
+        ell = self.config.lengthscale
+        if self.store_dtype != x.dtype:
+            if self._X_store is None:
+                self._X_store = self.X.to(self.store_dtype)
+            X, x = self._X_store, x.to(self.store_dtype)
+            if isinstance(ell, torch.Tensor):
+                ell = ell.to(self.store_dtype)
         es = x.element_size()
         budget = _PANEL_BYTES
         if x.is_cuda:
@@ -116,12 +144,11 @@ class _SymPackBlock:
         for a in range(lo, hi, rpp):
             b = min(hi, a + rpp)
             panel = be.kernel_materialize(
-                self.kind, self.X[a:b], self.X, self.config.lengthscale, scale=self.scale,
-                out=self._panel[: b - a],
+                self.kind, X[a:b], X, ell, scale=self.scale, out=self._panel[: b - a],
             )
             out[a - lo : b - lo] = be.matmat(panel, x)
         self._panel = None  # the panel is only needed while a sketch is being built
-        return out
+        return out.to(out_dtype)
 
     def release(self):
         self._Kp = None
@@ -223,7 +250,7 @@ class _KernelLinOp(TwoSidedLinOp, ScaleMixin):
     @property
     def storage_mode(self) -> str:
         if self._sym is not None:
-            return "sympack"
+            return "sympack" if self._sym.store_dtype == self.dtype else "sympack(float32 storage)"
         return "materialize" if self._block.materialised else "matrix_free"
 
     def _sym_matmat(self, x, diag_shift=0.0):
@@ -410,7 +437,7 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
     @property
     def storage_mode(self) -> str:
         if self._sym is not None:
-            return "sympack"
+            return "sympack" if self._sym.store_dtype == self.dtype else "sympack(float32 storage)"
         ids = self._local_ids()
         shard = self._A[ids[0]] if ids else None
         if isinstance(shard, _KernelShard):

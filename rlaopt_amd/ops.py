@@ -191,37 +191,44 @@ class HipBackend:
         return out[:, 0] if squeeze else out
 
     # -- symmetric packed kernel matrices ------------------------------------------------------
-    def sympack_materialize(self, kind, X, lengthscale, scale=1.0, first=0, stride=1):
-        """Strip-packed upper triangle of scale * K(X, X) (strips first, first+stride, ...)."""
+    def sympack_materialize(self, kind, X, lengthscale, scale=1.0, first=0, stride=1, store_dtype=None):
+        """Strip-packed upper triangle of scale * K(X, X) (strips first, first+stride, ...).
+        ``store_dtype=torch.float32`` with float64 X keeps the entries in float32."""
         dev, kid, X, ld, _X2, _ld2, ell, ell_vec, _i1, _i2, n, _n2 = self._kernel_common(
             kind, X, X, lengthscale, None, None
         )
-        elems = self._lib.rk_sympack_elems(_dt(X), n, first, stride)
-        Kp = torch.empty(max(elems, 1), dtype=X.dtype, device=dev)
+        store_dtype = store_dtype or X.dtype
+        elems = self._lib.rk_sympack_elems(_DT[store_dtype], n, first, stride)
+        Kp = torch.empty(max(elems, 1), dtype=store_dtype, device=dev)
         rc = self._lib.rk_kernel_materialize_sympack(
-            _dt(X), kid, _ptr(X), n, ld, X.shape[1], ell, _ptr(ell_vec), float(scale), first,
-            stride, _ptr(Kp), _stream(dev),
+            _dt(X), _DT[store_dtype], kid, _ptr(X), n, ld, X.shape[1], ell, _ptr(ell_vec),
+            float(scale), first, stride, _ptr(Kp), _stream(dev),
         )
         _lib.check(rc, "rk_kernel_materialize_sympack")
         return Kp
 
     def symm_matmat(self, Kp, n, V, alpha=1.0, diag_shift=0.0, first=0, stride=1, tag=None):
-        """alpha * (this rank's partial of) K V + diag_shift * V from the packed triangle."""
+        """alpha * (this rank's partial of) K V + diag_shift * V from the packed triangle; the
+        arithmetic type is V's dtype, the storage type Kp's (float32 storage under float64 V)."""
         dev = _req(Kp, V)
         V2, squeeze = _as2d(V)
-        if V2.shape[0] != n or V2.dtype != Kp.dtype:
-            raise ValueError("V must be (n x k) with the dtype of the packed matrix")
+        if V2.shape[0] != n:
+            raise ValueError("V must have n rows")
+        if not (V2.dtype == Kp.dtype or (V2.dtype == torch.float64 and Kp.dtype == torch.float32)):
+            raise ValueError("V must have the dtype of the packed matrix (or float64 over float32 storage)")
         V2, ldv = _rowmajor(V2)
         k = V2.shape[1]
-        out = torch.empty((n, k), dtype=Kp.dtype, device=dev)
+        out = torch.empty((n, k), dtype=V2.dtype, device=dev)
         es = V2.element_size()
         for c0 in range(0, k, 4):
             kc = min(4, k - c0)
-            ws, wsn = self._workspace(dev, self._lib.rk_symm_matmat_ws_bytes(_dt(Kp), n, kc, first, stride))
-            algo = (Kp.numel() + 2 * n * kc) * es  # packed triangle once + V + Y
+            ws, wsn = self._workspace(
+                dev, self._lib.rk_symm_matmat_ws_bytes(_dt(V2), _dt(Kp), n, kc, first, stride)
+            )
+            algo = Kp.numel() * Kp.element_size() + 2 * n * kc * es  # packed triangle once + V + Y
             with self._timed(tag or "rk_symm_matmat", dev, algo):
                 rc = self._lib.rk_symm_matmat(
-                    _dt(Kp), _ptr(Kp), n, first, stride, V2.data_ptr() + c0 * es, kc, ldv,
+                    _dt(V2), _dt(Kp), _ptr(Kp), n, first, stride, V2.data_ptr() + c0 * es, kc, ldv,
                     float(alpha), float(diag_shift), out.data_ptr() + c0 * es, k, _ptr(ws), wsn,
                     _stream(dev),
                 )

@@ -27,10 +27,11 @@ class OracleBackend:
         return ok.kernel_matmat(kind, X1, X2, lengthscale, V, scale, idx1=idx1, idx2=idx2)
 
     # sympack stand-in: keeps the dense matrix restricted to this rank's strips (upper part)
-    def sympack_materialize(self, kind, X, lengthscale, scale=1.0, first=0, stride=1):
+    def sympack_materialize(self, kind, X, lengthscale, scale=1.0, first=0, stride=1, store_dtype=None):
         n = X.shape[0]
-        W = 256 if X.dtype == torch.float32 else 128
-        K = ok.kernel_matrix(kind, X, X, lengthscale, scale)
+        store_dtype = store_dtype or X.dtype
+        W = 256 if store_dtype == torch.float32 else 128
+        K = ok.kernel_matrix(kind, X, X, lengthscale, scale).to(store_dtype)
         keep = torch.zeros_like(K)
         for s in range(first, -(-n // W), stride):
             lo, hi = s * W, min(n, (s + 1) * W)
@@ -38,9 +39,9 @@ class OracleBackend:
         return keep.reshape(-1)
 
     def symm_matmat(self, Kp, n, V, alpha=1.0, diag_shift=0.0, first=0, stride=1, tag=None):
-        U = Kp.reshape(n, n)
-        W = 256 if U.dtype == torch.float32 else 128
+        W = 256 if Kp.dtype == torch.float32 else 128
         V2, sq = _two_d(V)
+        U = Kp.reshape(n, n).to(V2.dtype)
         Y = U @ V2  # row contributions of every stored entry
         for s in range(first, -(-n // W), stride):  # column contributions from above the diagonal block
             lo, hi = s * W, min(n, (s + 1) * W)

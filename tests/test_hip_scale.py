@@ -154,3 +154,38 @@ def test_fullsize_materialised_shard_matches_fused(be, full_problem):
     d = K[torch.arange(0, hi - lo, 997, device=DEV), lo + torch.arange(0, hi - lo, 997, device=DEV)]
     assert bool((d == 1.0).all())
     del K
+
+
+def test_float32_storage_float64_iteration(be, monkeypatch):
+    """RK_STORAGE_DTYPE=float32: the packed operator is K rounded to float32, all vectors and
+    accumulations are float64: products match the rounded matrix to 1e-13 and PCG converges to
+    1e-10 (a float32 solve of the same system stalls near eps_32 x cond)."""
+    from oracle import kernels as ok
+
+    n, d, r, k = 3000, 8, 96, 2
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(n, d, dtype=torch.float64, generator=g) / d**0.5
+    B = torch.randn(n, k, dtype=torch.float64, generator=g)
+    V = torch.randn(n, 3, dtype=torch.float64, generator=g)
+    Kt = ok.kernel_matrix("rbf", X, X, 1.0).float().double()  # the operator actually stored
+    Xd = X.to(DEV)
+    Kp = be.sympack_materialize("rbf", Xd, 1.0, store_dtype=torch.float32)
+    assert Kp.dtype == torch.float32
+    got = be.symm_matmat(Kp, n, V.to(DEV), diag_shift=0.5)
+    want = Kt @ V + 0.5 * V
+    assert got.dtype == torch.float64
+    assert float((got.cpu() - want).norm() / want.norm()) < 1e-13
+    monkeypatch.setenv("RK_STORAGE_DTYPE", "float32")
+    A = RBFLinOp(Xd, Xd, KernelConfig(lengthscale=1.0))
+    assert A.storage_mode == "sympack(float32 storage)" and A.dtype == torch.float64
+    reg = 1e-6 * n
+    cfg = PCGConfig(device=DEV, max_iters=400, atol=0.0, rtol=1e-10,
+                    precond_config=NystromConfig(rank=r, rho=reg, sketch="gauss"))
+    system = LinSys(A, B.to(DEV), reg=reg)
+    W, log = system.solve(cfg, torch.zeros(n, k, dtype=torch.float64, device=DEV), callback_freq=5)
+    assert float(log[max(log)]["metrics"]["internal_metrics"]["rel_res"].max()) <= 1e-10
+    Wref = torch.linalg.solve(Kt + reg * torch.eye(n, dtype=torch.float64), B)
+    assert float((W.cpu() - Wref).norm() / Wref.norm()) < 1e-6
+    # a wide product (sketch path) goes through float32 panels and comes back as float64
+    wide = A @ torch.randn(n, 40, dtype=torch.float64, generator=g).to(DEV)
+    assert wide.dtype == torch.float64 and wide.shape == (n, 40)
