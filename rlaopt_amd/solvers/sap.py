@@ -17,6 +17,7 @@ from typing import TYPE_CHECKING
 
 import torch
 
+from .. import dist as _dist
 from ..linops import LinOp
 from ..preconditioners import (
     IdentityConfig, NewtonConfig, NystromConfig, Preconditioner, PreconditionerConfig,
@@ -81,12 +82,12 @@ class SAP(Solver):
         # host (sap.py:76-86; 62 ms at n = 500 000, numpy fallback past 2**24 categories).  With
         # uniform probabilities that is a uniformly random subset: draw it as the head of a
         # random permutation on the solver's device (seeded from torch's default generator).
+        # In an SPMD run every rank must pick the SAME block: the seed comes from rank 0.
         n = self.probs.shape[0]
-        if self._W.is_cuda:
-            gen = torch.Generator(device=self._W.device)
-            gen.manual_seed(int(torch.randint(0, 2**62, (1,))))
-            return torch.randperm(n, device=self._W.device, generator=gen)[: self.blk_sz]
-        return torch.randperm(n)[: self.blk_sz]
+        seed = int(_dist.broadcast_object(int(torch.randint(0, 2**62, (1,)))))
+        gen = torch.Generator(device=self._W.device)
+        gen.manual_seed(seed)
+        return torch.randperm(n, device=self._W.device, generator=gen)[: self.blk_sz]
 
     def _get_stepsize(self, blk: torch.Tensor, blk_precond: Preconditioner) -> float:
         if isinstance(self.precond_config, NewtonConfig) and self.precond_config.rho == self.system.reg:

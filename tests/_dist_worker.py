@@ -96,6 +96,61 @@ def main():
         Wsum = W.clone()
         td.all_reduce(Wsum)
         torch.testing.assert_close(Wsum / size, W, rtol=1e-12, atol=1e-12)
+        # ---- SPMD sketch-and-project (distributed row / block oracles, replicated iterates) --------
+        from oracle import sap as osap
+        from rlaopt_amd.solvers import SAPAccelConfig, SAPConfig
+
+        blk_sz, rk, steps = 12, 6, 8
+        gsap = torch.Generator().manual_seed(123)
+        blocks = [torch.randperm(n, generator=gsap)[:blk_sz] for _ in range(steps)]
+        omegas = [(torch.randn(rk, blk_sz, dtype=dt, generator=gsap) / rk**0.5).T.contiguous() for _ in range(steps)]
+        starts = [torch.randn(blk_sz, dtype=dt, generator=gsap) for _ in range(steps)]
+        regs = 1e-2
+        Aop = DistributedRBFLinOp(X, X, KernelConfig(lengthscale=1.0), devices={cpu})
+        sysm = LinSys(Aop, B, reg=regs, A_row_oracle=Aop.row_oracle, A_blk_oracle=Aop.blk_oracle)
+        scfg = SAPConfig(device=cpu, max_iters=steps, atol=0.0, rtol=1e-14,
+                         precond_config=NystromConfig(rank=rk, rho=regs, sketch="gauss"), blk_sz=blk_sz,
+                         accel_config=SAPAccelConfig(mu=regs, nu=10.0))
+        import rlaopt_amd.models.linsys as ml
+
+        orig = ml._get_solver
+
+        def patched(model, W_init, solver_config):
+            sv = orig(model=model, W_init=W_init, solver_config=solver_config)
+            sv.inject_draws(blocks=blocks, starts=starts)
+            return sv
+
+        ml._get_solver = patched
+        try:
+            with sketches.inject(*omegas):
+                Wsap, _ = sysm.solve(scfg, torch.zeros_like(B), callback_freq=4)
+        finally:
+            ml._get_solver = orig
+        import torch as _t
+
+        _old = _t.get_default_dtype()
+        _t.set_default_dtype(dt)
+        try:
+            ref = osap.SAP(n, lambda b: Kd[b], lambda b: Kd[b][:, b], B, regs, torch.zeros_like(B),
+                           ("nystrom", rk, regs, "gauss", True), blk_sz=blk_sz, accel=True, mu=regs,
+                           nu=10.0, blk_sequence=blocks)
+            it_om, it_v0 = iter(omegas), iter(starts)
+            import oracle.sketches as osk2
+            import oracle.sap as osap_mod
+
+            real_sk = osk2.get_sketch_matrix
+            osk2.get_sketch_matrix = lambda *a, **k: next(it_om)
+            real_pow = osap_mod.randomized_powering
+            osap_mod.randomized_powering = lambda f, d_, dev_, max_iters=10, rtol=1e-3, v0=None: real_pow(
+                f, d_, dev_, max_iters=max_iters, rtol=rtol, v0=next(it_v0))
+            try:
+                for _ in range(steps):
+                    ref.step(torch.ones(k, dtype=torch.bool))
+            finally:
+                osk2.get_sketch_matrix, osap_mod.randomized_powering = real_sk, real_pow
+        finally:
+            _t.set_default_dtype(_old)
+        torch.testing.assert_close(Wsap, ref.W, rtol=1e-8, atol=1e-10)
     td.barrier()
     if rank == 0:
         print(f"DIST-OK world={size} n={n} iters={max(log)}")
