@@ -112,7 +112,8 @@ sympack_materialize_kernel(int kind, const T* __restrict__ X, int64_t ldx, int64
 template <typename TS, typename T, int K>
 __global__ void __launch_bounds__(256)
 symm_strip_kernel(const TS* __restrict__ Kp, SymLayout L, const T* __restrict__ V, int64_t ldv,
-                  T* __restrict__ Prow, T* __restrict__ Pcol, int64_t max_items) {
+                  T* __restrict__ Prow, T* __restrict__ Pcol, int64_t max_items,
+                  int64_t total_items) {
     using V16 = typename Vec16<TS>::type;
     constexpr int VW = Vec16<TS>::N;
     constexpr int W = strip_width<TS>();
@@ -121,12 +122,22 @@ symm_strip_kernel(const TS* __restrict__ Kp, SymLayout L, const T* __restrict__ 
     __shared__ T rowbuf[4][WAVE_ROWS][K];
     __shared__ T colbuf[4][W][K];
 
-    const int64_t t = blockIdx.y;
-    const int64_t nrows = L.rows(t);
-    const int64_t item_lo = (int64_t)blockIdx.x * ITEM_ROWS;
-    if (item_lo >= nrows) return;  // uniform over the workgroup, before any barrier
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Persistent workgroups: items (strip, 1024-row chunk) are numbered strip by strip; this
+    // workgroup takes the ids blockIdx.x, blockIdx.x + gridDim.x, ... (equal-sized items, no
+    // empty workgroups for the triangle's short strips).  (t, before) walks forward with the id.
+    int64_t t = 0, before = 0;
+  for (int64_t id = blockIdx.x; id < total_items; id += gridDim.x) {
+    for (;;) {
+        const int64_t cnt = (L.rows(t) + ITEM_ROWS - 1) / ITEM_ROWS;
+        if (id < before + cnt) break;
+        before += cnt;
+        ++t;
+    }
+    const int64_t chunk = id - before;
+    const int64_t nrows = L.rows(t);
+    const int64_t item_lo = chunk * ITEM_ROWS;
     const int64_t s = L.strip(t);
     const int64_t diag_lo = s * W;  // rows >= diag_lo belong to the (fully stored) diagonal block
     const TS* base = Kp + L.row_offset(t) * W;
@@ -207,11 +218,13 @@ symm_strip_kernel(const TS* __restrict__ Kp, SymLayout L, const T* __restrict__ 
     for (int e = lane; e < (int)(r_hi > r_lo ? (r_hi - r_lo) : 0) * K; e += 64)
         Prow[prow0 * K + e] = rowbuf[wave][e / K][e % K];
     // column sums of the 4 waves -> Pcol[item]
-    T* pc = Pcol + ((t * max_items + blockIdx.x) * W) * K;
+    T* pc = Pcol + ((t * max_items + chunk) * W) * K;
     for (int e = threadIdx.x; e < W * K; e += 256) {
         const int j = e / K, c = e - j * K;
         pc[e] = ((colbuf[0][j][c] + colbuf[1][j][c]) + colbuf[2][j][c]) + colbuf[3][j][c];
     }
+    __syncthreads();  // rowbuf / colbuf are reused by the next item
+  }
 }
 
 // Y[i][c] = alpha * (row parts of every local strip that stores row i
@@ -316,10 +329,13 @@ static int symm_matmat_impl(const TS* Kp, int64_t n, int64_t first, int64_t stri
     T* Prow = static_cast<T*>(ws);
     T* Pcol = Prow + (size_t)L.total_rows() * k;
     if (T_loc > 0) {
-        dim3 grid((unsigned)ceil_div(L.rows(T_loc - 1), ITEM_ROWS), (unsigned)T_loc);
+        int64_t total_items = 0;
+        for (int64_t t = 0; t < T_loc; ++t) total_items += ceil_div(L.rows(t), ITEM_ROWS);
+        const int64_t resident = 256 * 6;  // CUs x workgroups per CU
+        dim3 grid((unsigned)(total_items < resident ? total_items : resident));
 #define RK_SYMM(KK)                                                                             \
     hipLaunchKernelGGL((symm_strip_kernel<TS, T, KK>), grid, dim3(256), 0, st, Kp, L, V, ldv, Prow, \
-                       Pcol, max_items)
+                       Pcol, max_items, total_items)
         switch (k) {
             case 1: RK_SYMM(1); break;
             case 2: RK_SYMM(2); break;
