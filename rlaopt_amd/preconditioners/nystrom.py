@@ -105,9 +105,9 @@ class Nystrom(Preconditioner):
             self.L = None
 
     # -- apply ---------------------------------------------------------------------------------
-    def _project(self, X):
+    def _project(self, X, out_f64=False):
         """U^T X (summed over row shards)."""
-        t = get_backend().rmatmat(self.U, X)
+        t = get_backend().rmatmat(self.U, X, out_f64=out_f64)
         if self._sharded:
             _dist.all_reduce_sum(t, self._group)
         return t
@@ -139,19 +139,19 @@ class Nystrom(Preconditioner):
                     Lk = torch.linalg.cholesky(0.5 * (small + small.T))
                     Minv[keep[:, None], keep[None, :]] = torch.cholesky_inverse(Lk)
                 self.L = Lk.to(device=dev, dtype=dt)
-            self._M = Minv.to(device=dev, dtype=dt)
+            self._M = Minv.to(device=dev)  # float64: the r x r step is applied in float64
         else:
-            self._M = (S64 / (S64 + rho)).to(device=dev, dtype=dt)
+            self._M = (S64 / (S64 + rho)).to(device=dev)
         return self._M
 
     def _inverse_matmul_general(self, x: torch.Tensor, unsqueeze: bool) -> torch.Tensor:
         be = get_backend()
         X = x[:, None] if unsqueeze else x
         M = self._apply_factor()
-        t = self._project(X)
+        t = self._project(X, out_f64=True)  # r x k, float64
         t = be.matmat(M, t) if M.ndim == 2 else t * M[:, None]
         inv_rho = 1.0 / float(self.config.rho)
-        out = be.matmat(self.U, t, alpha=-inv_rho, beta=inv_rho, C=X)
+        out = be.matmat(self.U, t.to(X.dtype), alpha=-inv_rho, beta=inv_rho, C=X)
         return out[:, 0] if unsqueeze else out
 
     def _inverse_matmul_1d(self, x):

@@ -22,7 +22,8 @@ class SkPre(Preconditioner):
         super().__init__(config)
         self.Y = None
         self.L = None
-        self._Linv = None
+        self._L64 = None
+        self._Linv64 = None
 
     def _update(self, A, device):
         if self.config.sketch_size < A.shape[1]:
@@ -42,16 +43,23 @@ class SkPre(Preconditioner):
         with small_host_lapack(G.shape[0]):
             L = torch.linalg.cholesky(G, upper=False)
             Linv = torch.linalg.solve_triangular(L, torch.eye(L.shape[0], dtype=torch.float64), upper=False)
-        self.L = L.to(device=device, dtype=A.dtype)
-        self._Linv = Linv.to(device=device, dtype=A.dtype)
+        self.L = L.to(device=device, dtype=A.dtype)  # the attribute the reference exposes
+        # The d x d factors are applied in float64 whatever the working dtype (the vectors they
+        # act on are d-long: free), so that P (P^-1 x) = x holds to working precision even for
+        # the ill-conditioned Gram matrices of a too-small sketch; results are cast back.
+        self._L64 = L.to(device=device)
+        self._Linv64 = Linv.to(device=device)
+
+    def _apply64(self, fn, x):
+        return fn(x.double()).to(x.dtype)
 
     def _matmul(self, x):
         be = get_backend()
-        return be.rmatmat(self.L, be.matmat(self.L, x))  # L^T (L x)
+        return self._apply64(lambda v: be.rmatmat(self._L64, be.matmat(self._L64, v)), x)  # L^T (L x)
 
     def _solve(self, x):
         be = get_backend()
-        return be.matmat(self._Linv, be.rmatmat(self._Linv, x))  # L^-1 (L^-T x)
+        return self._apply64(lambda v: be.matmat(self._Linv64, be.rmatmat(self._Linv64, v)), x)
 
     _inverse_matmul_1d = _solve
     _inverse_matmul_2d = _solve
@@ -59,8 +67,8 @@ class SkPre(Preconditioner):
     # split factors for RIGHT preconditioning (LSQR on A R^-1 with R = L^T, G = L L^T):
     def _right_solve(self, x):
         """R^-1 x = L^-T x."""
-        return get_backend().rmatmat(self._Linv, x)
+        return self._apply64(lambda v: get_backend().rmatmat(self._Linv64, v), x)
 
     def _right_solve_t(self, x):
         """R^-T x = L^-1 x."""
-        return get_backend().matmat(self._Linv, x)
+        return self._apply64(lambda v: get_backend().matmat(self._Linv64, v), x)
