@@ -2,7 +2,7 @@
 """Headline benchmark: PCG iterations/s (and kernel-matvec GB/s) on the n = 200 000 RBF KRR
 system of BASELINE.json, row-sharded over N MI355X GPUs.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -105,8 +105,8 @@ def committed_traffic(world, n, mode):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=200000)
     ap.add_argument("--d", type=int, default=64)
     ap.add_argument("--rank", type=int, default=512)
@@ -191,12 +191,17 @@ def main():
     for i in range(1, args.warmup + 1):
         one_iteration(i)
     be.enable_timing(True)  # fresh table for the timed region
+    import gc
+
+    gc.collect()
+    gc.disable()  # no collector pauses on the host inside the timed region
     sync()
     t0 = time.perf_counter()
     for i in range(args.warmup + 1, args.warmup + args.steps + 1):
         one_iteration(i)
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     timing = be.timing_summary()
     be.enable_timing(False)
     if world > 1:

@@ -7,8 +7,8 @@ OUT=gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout -k 10 600 python -m pytest tests -m gpu -q -x > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest EXIT $?"; tail -3 $OUT/${TAG}_pytest_gpu.log
-timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_n1.log 2>&1 && echo "bench ok" && tail -1 $OUT/${TAG}_bench_n1.log | cut -c1-400
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o ${TAG} -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-solve > $OUT/${TAG}_bench_under_rocprof.log 2>&1 && echo "rocprof stats ok"
+timeout -k 10 300 python bench.py > $OUT/${TAG}_bench_n1.log 2>&1 && echo "bench ok" && tail -1 $OUT/${TAG}_bench_n1.log | cut -c1-400
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o ${TAG} -- python3 bench.py --no-cpu-baseline --no-solve > $OUT/${TAG}_bench_under_rocprof.log 2>&1 && echo "rocprof stats ok"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o ${TAG} -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-solve > $OUT/${TAG}_pmc_fetch.log 2>&1 && echo "pmc fetch ok"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o ${TAG} -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-solve > $OUT/${TAG}_pmc_write.log 2>&1 && echo "pmc write ok"
 ls -R $OUT | grep -c csv

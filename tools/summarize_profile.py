@@ -57,7 +57,7 @@ out = {
 }
 json.dump(out, open(f"{dst}/{tag}_traffic.json", "w"), indent=1)
 with open(f"{dst}/{tag}_summary.md", "w") as f:
-    f.write(f"# rocprofv3 summary `{tag}` - `bench.py --steps 20 --warmup 5` on one MI355X\n\n")
+    f.write(f"# rocprofv3 summary `{tag}` - `bench.py` (defaults) on one MI355X\n\n")
     f.write(f"bench line: value {bench['value']:.2f} iter/s, {bench['ms_per_step']:.2f} ms/step; "
             f"roofline achieved {bench['roofline']['achieved']:.0f} GB/s "
             f"({100 * bench['roofline']['frac']:.1f} % of 8000), avg launch "
