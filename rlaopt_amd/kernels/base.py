@@ -138,6 +138,10 @@ class _SymPackBlock:
         if x.is_cuda:
             budget = min(budget, int(0.5 * torch.cuda.mem_get_info(x.device)[0]))
         rpp = max(256, min(hi - lo, budget // (self.n * es)))
+        # 128 x 128 GEMM tiles, 4 column tiles for a rank-512 sketch: a multiple of 8192 rows gives
+        # a multiple of 256 tiles = whole rounds of the 256 CUs (no partial last round)
+        if rpp >= 8192:
+            rpp -= rpp % 8192
         if self._panel is None or self._panel.shape[0] < min(rpp, hi - lo):
             self._panel = torch.empty((min(rpp, hi - lo), self.n), dtype=x.dtype, device=x.device)
         out = torch.empty((hi - lo, x.shape[1]), dtype=x.dtype, device=x.device)
