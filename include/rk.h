@@ -195,6 +195,20 @@ int rk_small_solve(int64_t k, int64_t nrhs, const double* A, const double* B, do
                    void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Sparse-sign sketch  [a7, a10]
+ * ---------------------------------------------------------------------------------- */
+
+/* Y (s x d) = scale * Omega @ A for the sparse-sign embedding Omega (s x m, <= zeta signed
+ * entries per column; rlaopt/sketches/sparse.py:52-76) given in row-sorted form: entries
+ * row_ptr[r] .. row_ptr[r+1]-1 of `col` (int32 row index into A) and `sgn` (+1 / -1) belong to
+ * sketch row r.  Replaces the dense `Omega_mat @ A` of rlaopt/sketches/sketch.py:75-84 in the
+ * SkPre update (rlaopt/preconditioners/skpre.py:84): zeta passes over A instead of an
+ * s x m x d GEMM, and no dense s x m matrix. */
+int rk_sparse_sign_apply(int dtype, const void* A, int64_t m, int64_t d, int64_t lda,
+                         const int* col, const signed char* sgn, const int64_t* row_ptr, int64_t s,
+                         double scale, void* Y, int64_t ldy, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Gaussian test matrices  [a7]
  * ---------------------------------------------------------------------------------- */
 

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "librk_hip.so")
 
 RK_F32, RK_F64 = 0, 1
 KIND_IDS = {"rbf": 0, "laplace": 1, "matern12": 2, "matern32": 3, "matern52": 4}
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # name -> (restype, argtypes); must list every symbol declared in include/rk.h
 SIGNATURES = {
@@ -89,6 +89,11 @@ SIGNATURES = {
         c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
     ),
     "rk_small_solve": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rk_sparse_sign_apply": (
+        c_int,
+        [c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_double,
+         c_void_p, c_int64, c_void_p],
+    ),
     "rk_randn": (
         c_int, [c_int, c_void_p, c_int64, c_int64, c_int64, c_uint64, c_uint64, c_double, c_void_p]
     ),

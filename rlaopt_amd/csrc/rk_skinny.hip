@@ -482,6 +482,74 @@ gram_small_finish(const double* __restrict__ part, int nblocks, int kk, double* 
     if (threadIdx.x == 63) G[e] = s;
 }
 
+// ------------------------------------------------------------------------------------------
+// Sparse-sign sketch apply  Y (s x d) = scale * Omega A  for Omega (s x m) with <= zeta signed
+// entries per COLUMN (rlaopt/sketches/sparse.py:52-76), given in row-sorted (CSR) form:
+// Y[r, :] = scale * sum_{e in row r} sign[e] * A[col[e], :].  A gather of whole rows (1 KiB
+// per wave load), no atomics, fixed summation order: each A row is read zeta times instead of
+// multiplying by a dense s x m matrix (zeta / s of the flops, none of its 8 s m bytes).
+// One workgroup per (sketch row, 64 x 16 B column chunk); its 4 waves split the row's entries.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+sparse_sign_apply_kernel(const T* __restrict__ A, int64_t d, int64_t lda,
+                         const int* __restrict__ col, const signed char* __restrict__ sgn,
+                         const int64_t* __restrict__ row_ptr, T scale, T* __restrict__ Y,
+                         int64_t ldy) {
+    using V16 = typename Vec16<T>::type;
+    constexpr int VW = Vec16<T>::N;
+    constexpr int UNR = 8;
+    __shared__ T red[4][kWave * VW];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t r = blockIdx.y;
+    const int64_t j = ((int64_t)blockIdx.x * kWave + lane) * VW;
+    const bool vec = (j + VW <= d) && (lda % VW == 0);
+    const int64_t e_lo = row_ptr[r], e_hi = row_ptr[r + 1];
+    const int64_t per = (e_hi - e_lo + 3) / 4;
+    const int64_t lo = e_lo + wave * per;
+    const int64_t hi = (lo + per < e_hi) ? lo + per : e_hi;
+    T acc[VW];
+#pragma unroll
+    for (int q = 0; q < VW; ++q) acc[q] = T(0);
+    int64_t e = lo;
+    if (vec) {
+        for (; e + UNR <= hi; e += UNR) {
+            V16 a[UNR];
+            T sg[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                a[u] = *reinterpret_cast<const V16*>(A + (int64_t)col[e + u] * lda + j);
+                sg[u] = (T)sgn[e + u];
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const T* ae = reinterpret_cast<const T*>(&a[u]);
+#pragma unroll
+                for (int q = 0; q < VW; ++q) acc[q] += sg[u] * ae[q];
+            }
+        }
+    }
+    for (; e < hi; ++e) {
+        const T* row = A + (int64_t)col[e] * lda;
+        const T sg = (T)sgn[e];
+#pragma unroll
+        for (int q = 0; q < VW; ++q)
+            if (j + q < d) acc[q] += sg * row[j + q];
+    }
+#pragma unroll
+    for (int q = 0; q < VW; ++q) red[wave][lane * VW + q] = acc[q];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < VW; ++q) {
+            const int idx = lane * VW + q;
+            if (j + q < d)
+                Y[r * ldy + j + q] = scale * (((red[0][idx] + red[1][idx]) + red[2][idx]) + red[3][idx]);
+        }
+    }
+}
+
 // Y[:, c] = a[c] * X[:, c] + b[c] * Y[:, c] with device-resident float64 coefficients
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -912,6 +980,27 @@ extern "C" int rk_gram_small(int dtype, const void* X, int64_t ldx, const void* 
     hipLaunchKernelGGL(gram_small_finish, dim3((unsigned)(k1 * k2)), dim3(64), 0, st, part, nb,
                        (int)(k1 * k2), G);
     return launch_status("rk_gram_small(finish)");
+}
+
+extern "C" int rk_sparse_sign_apply(int dtype, const void* A, int64_t m, int64_t d, int64_t lda,
+                                    const int* col, const signed char* sgn, const int64_t* row_ptr,
+                                    int64_t s, double scale, void* Y, int64_t ldy, void* stream) {
+    clear_error();
+    RK_REQUIRE(dtype == RK_F32 || dtype == RK_F64, "rk_sparse_sign_apply: bad dtype %d", dtype);
+    RK_REQUIRE(A && col && sgn && row_ptr && Y, "rk_sparse_sign_apply: null pointer");
+    RK_REQUIRE(m > 0 && d > 0 && s > 0 && s <= 65535, "rk_sparse_sign_apply: bad sizes (s <= 65535)");
+    RK_REQUIRE(lda >= d && ldy >= d, "rk_sparse_sign_apply: leading dimension too small");
+    RK_REQUIRE(aligned16(A), "rk_sparse_sign_apply: A must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int vw = dtype == RK_F32 ? 4 : 2;
+    dim3 grid((unsigned)ceil_div(d, (int64_t)kWave * vw), (unsigned)s);
+    if (dtype == RK_F32)
+        hipLaunchKernelGGL((sparse_sign_apply_kernel<float>), grid, dim3(256), 0, st, (const float*)A,
+                           d, lda, col, sgn, row_ptr, (float)scale, (float*)Y, ldy);
+    else
+        hipLaunchKernelGGL((sparse_sign_apply_kernel<double>), grid, dim3(256), 0, st,
+                           (const double*)A, d, lda, col, sgn, row_ptr, scale, (double*)Y, ldy);
+    return launch_status("rk_sparse_sign_apply");
 }
 
 extern "C" int rk_axpby_cols(int dtype, int64_t n, int64_t k, const void* X, int64_t ldx,

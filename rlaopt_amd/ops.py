@@ -414,6 +414,22 @@ class HipBackend:
         _lib.check(rc, "rk_small_solve")
         return X
 
+    def sparse_sign_apply(self, A, col, sgn, row_ptr, scale):
+        """scale * Omega @ A for a row-sorted sparse-sign embedding (see include/rk.h)."""
+        dev = _req(A, col, sgn, row_ptr)
+        A, lda = _rowmajor(A)
+        m, d = A.shape
+        s = row_ptr.numel() - 1
+        if col.dtype != torch.int32 or sgn.dtype != torch.int8 or row_ptr.dtype != torch.int64:
+            raise ValueError("col must be int32, sgn int8, row_ptr int64")
+        Y = torch.empty((s, d), dtype=A.dtype, device=dev)
+        rc = self._lib.rk_sparse_sign_apply(
+            _dt(A), _ptr(A), m, d, lda, _ptr(col.contiguous()), _ptr(sgn.contiguous()),
+            _ptr(row_ptr.contiguous()), s, float(scale), _ptr(Y), d, _stream(dev),
+        )
+        _lib.check(rc, "rk_sparse_sign_apply")
+        return Y
+
     def randn(self, rows, cols, dtype, device, seed, offset=0, scale=1.0):
         device = torch.device(device)
         if device.type != "cuda":

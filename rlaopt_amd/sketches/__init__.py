@@ -96,13 +96,28 @@ class Sketch(ABC):
         self.s, self.d, self.dtype, self.device = sketch_size, matrix_dim, dtype, device
         _is_pos_int(sketch_size, "sketch_size")
         want = (self.s, self.d) if self.mode is _SketchSide.LEFT else (self.d, self.s)
+        self._sparse = None  # (col int32, sgn int8, row_ptr int64, scale) for sparse-sign sketches
         if _injected:
             Om = _injected.popleft()
             if tuple(Om.shape) != want:
                 raise ValueError(f"injected sketch has shape {tuple(Om.shape)}, expected {want}")
-            self.Omega_mat = Om.to(device=device, dtype=dtype)
+            self._Omega = Om.to(device=device, dtype=dtype)
         else:
-            self.Omega_mat = self._generate_embedding()
+            self._Omega = self._generate_embedding()
+
+    @property
+    def Omega_mat(self) -> torch.Tensor:
+        """The embedding as a dense tensor (built on first use for structured sketches)."""
+        if self._Omega is None:
+            self._Omega = self._densify()
+        return self._Omega
+
+    @Omega_mat.setter
+    def Omega_mat(self, value: torch.Tensor):
+        self._Omega = value
+
+    def _densify(self) -> torch.Tensor:
+        raise NotImplementedError
 
     @abstractmethod
     def _generate_embedding(self) -> torch.Tensor: ...
@@ -161,21 +176,45 @@ class Ortho(Sketch):
 
 
 class Sparse(Sketch):
-    """Sparse sign embedding: zeta = min(8, s) entries of +-zeta^-1/2 per column of the
-    (s, d) matrix, colliding positions overwrite (sparse.py:52-76).  Generated with torch's
-    device RNG (O(zeta d) work, outside the hot path); applied as a dense matrix like the
-    reference does."""
+    """Sparse sign embedding: zeta = min(8, s) entries of +-zeta^-1/2 per column of the (s, d)
+    matrix, colliding positions overwrite (sparse.py:52-76; one of the colliding draws survives,
+    here the last one).  The structure is kept in row-sorted form; ``Omega @ A`` for a tensor A
+    (the SkPre update) runs as a gather of rows of A (``rk_sparse_sign_apply``: zeta passes over
+    A, no dense s x d matrix).  ``Omega_mat`` densifies on demand for every other use, like
+    the reference.  The draws use torch's device RNG (O(zeta d) work, outside the hot path)."""
 
     def _generate_embedding(self):
-        zeta = 8 if self.s >= 8 else self.s
+        s, d, dev = self.s, self.d, self.device
+        zeta = 8 if s >= 8 else s
+        signs = 2 * torch.bernoulli(torch.full((zeta, d), 0.5, dtype=self.dtype, device=dev)) - 1
+        rows = torch.randint(s, (zeta, d), device=dev)
+        keep = torch.ones((zeta, d), dtype=torch.bool, device=dev)
+        for t in range(zeta - 1):  # entry t is overwritten by a later draw on the same row
+            keep[t] &= ~(rows[t + 1 :] == rows[t]).any(dim=0)
+        self._zeta = zeta
+        tgt = rows[keep]
+        cols = torch.arange(d, device=dev).expand(zeta, d)[keep]
+        sg = signs[keep]
+        order = torch.argsort(tgt, stable=True)
+        counts = torch.bincount(tgt, minlength=s)
+        row_ptr = torch.zeros(s + 1, dtype=torch.int64, device=dev)
+        row_ptr[1:] = torch.cumsum(counts, 0)
+        self._sparse = (cols[order].to(torch.int32), sg[order].to(torch.int8), row_ptr, zeta**-0.5)
+        self._coo = (tgt, cols, sg)
+        return None  # dense form on demand
+
+    def _densify(self):
+        tgt, cols, sg = self._coo
         Om = torch.zeros((self.s, self.d), dtype=self.dtype, device=self.device)
-        signs = 2 * torch.bernoulli(
-            torch.full((zeta, self.d), 0.5, dtype=self.dtype, device=self.device)
-        ) - 1
-        rows = torch.randint(self.s, (zeta, self.d), device=self.device)
-        Om.scatter_(0, rows, signs)
-        Om = Om * zeta**-0.5
+        Om[tgt, cols] = sg * self._zeta**-0.5
         return Om.T.contiguous() if self.mode is _SketchSide.RIGHT else Om
+
+    def _apply_left(self, x):
+        if (self._sparse is not None and self.mode is _SketchSide.LEFT
+                and isinstance(x, torch.Tensor) and x.ndim == 2):
+            col, sgn, row_ptr, scale = self._sparse
+            return get_backend().sparse_sign_apply(x, col, sgn, row_ptr, scale)
+        return super()._apply_left(x)
 
 
 SKETCH_MODE_TO_CLASS = {_SketchMode.GAUSS: Gauss, _SketchMode.ORTHO: Ortho, _SketchMode.SPARSE: Sparse}

@@ -91,6 +91,13 @@ class OracleBackend:
     def small_solve(self, A, B):
         return torch.linalg.solve(A, B)
 
+    def sparse_sign_apply(self, A, col, sgn, row_ptr, scale):
+        s = row_ptr.numel() - 1
+        Y = torch.zeros((s, A.shape[1]), dtype=A.dtype)
+        rows = torch.repeat_interleave(torch.arange(s), row_ptr[1:] - row_ptr[:-1])
+        Y.index_add_(0, rows, A[col.long()] * sgn.to(A.dtype)[:, None])
+        return scale * Y
+
     def randn(self, rows, cols, dtype, device, seed, offset=0, scale=1.0):
         g = torch.Generator().manual_seed((int(seed) * 1000003 + int(offset)) % (2**63))
         return scale * torch.randn(rows, cols, dtype=dtype, generator=g).to(device)

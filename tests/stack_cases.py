@@ -369,3 +369,31 @@ def test_least_squares_lsqr_matches_oracle(dev, prec, reg, precond):
         assert max(log) <= 40  # sketch-and-precondition: condition number O(1)
     err = float((W.cpu().double() - want).norm() / want.norm())
     assert err < (1e-6 if f64 else 5e-2), err
+
+
+def test_sparse_sign_sketch_structure_and_fast_apply(dev, prec):
+    """Sparse-sign embedding (sparse.py:52-76): <= 8 entries of +-8^-1/2 per column, and the
+    row-gather apply equals the dense product."""
+    from rlaopt_amd.sketches import get_sketch
+
+    dt = DTYPES[prec]
+    torch.manual_seed(3)
+    s, m, d = 64, 3000, 40
+    sk = get_sketch("sparse", "left", s, m, dt, dev)
+    A = torch.randn(m, d, dtype=dt, generator=torch.Generator().manual_seed(1)).to(dev)
+    fast = sk._apply_left(A)
+    Om = sk.Omega_mat
+    assert Om.shape == (s, m) and Om.dtype == dt
+    nnz = (Om != 0).sum(0)
+    assert int(nnz.max()) <= 8 and int(nnz.min()) >= 1
+    vals = Om[Om != 0].abs()
+    torch.testing.assert_close(vals, torch.full_like(vals, 8**-0.5))
+    want = Om.double().cpu() @ A.double().cpu()
+    tol = 1e-12 if dt == torch.float64 else 2e-5
+    assert float((fast.double().cpu() - want).norm() / want.norm()) < tol
+    # E[Omega^T Omega] = I: column norms are 1 up to collisions
+    cn = (Om.double() ** 2).sum(0)
+    assert float(cn.mean()) > 0.9 and float(cn.max()) <= 1.0 + 1e-12
+    # right mode and small sketches keep the dense path
+    skr = get_sketch("sparse", "right", 4, 50, dt, dev)
+    assert skr.Omega_mat.shape == (50, 4) and int((skr.Omega_mat != 0).sum(1).max()) <= 4
