@@ -36,6 +36,37 @@ def main():
     cpu = torch.device("cpu")
     dt = torch.float64
     gen = torch.Generator().manual_seed(0)
+    if n < 10:
+        # fewer row blocks than ranks (torch.chunk(arange(4), 3) has 2 blocks): the last rank owns
+        # no rows and must still take part in every collective (kernels/base.py:297-307)
+        with use_backend(OracleBackend()):
+            X = torch.randn(n, 3, dtype=dt, generator=gen)
+            X2 = torch.randn(n + 1, 3, dtype=dt, generator=gen)
+            M = torch.randn(n + 1, 2, dtype=dt, generator=gen)
+            u = torch.randn(n, 2, dtype=dt, generator=gen)
+            cfgk = KernelConfig(lengthscale=1.1)
+            op = DistributedRBFLinOp(X, X2, cfgk, devices={cpu})
+            K = ok.kernel_matrix("rbf", X, X2, 1.1)
+            lo, hi = op.row_range
+            assert (hi - lo == 0) == (rank >= len(rdist.row_chunks(n, size)))
+            torch.testing.assert_close(op @ M, K @ M, rtol=1e-10, atol=1e-12)
+            torch.testing.assert_close(op.T @ u, K.T @ u, rtol=1e-10, atol=1e-12)
+            blk = torch.tensor([n - 1, 0])
+            torch.testing.assert_close(op.row_oracle(blk) @ M, K[blk] @ M, rtol=1e-10, atol=1e-12)
+            sq = DistributedRBFLinOp(X, X, cfgk, devices={cpu})
+            Ksq = ok.kernel_matrix("rbf", X, X, 1.1)
+            torch.testing.assert_close(sq @ u, Ksq @ u, rtol=1e-10, atol=1e-12)
+            w = torch.randn(2, 2, dtype=dt, generator=gen)
+            torch.testing.assert_close(sq.blk_oracle(blk) @ w, Ksq[blk][:, blk] @ w, rtol=1e-10, atol=1e-12)
+            B = torch.randn(n, 1, dtype=dt, generator=gen)
+            W, log = LinSys(sq, B, reg=0.5).solve(PCGConfig(device=cpu, max_iters=20, rtol=1e-12), torch.zeros(n, 1, dtype=dt), callback_freq=1)
+            want = torch.linalg.solve(Ksq + 0.5 * torch.eye(n, dtype=dt), B)
+            torch.testing.assert_close(W, want, rtol=1e-8, atol=1e-10)
+        td.barrier()
+        if rank == 0:
+            print(f"DIST-OK world={size} n={n} (fewer blocks than ranks)")
+        td.destroy_process_group()
+        return
     d, k, r = 5, 2, 24
     X = torch.randn(n, d, dtype=dt, generator=gen) / d**0.5
     X2 = torch.randn(n - 3, d, dtype=dt, generator=gen) / d**0.5

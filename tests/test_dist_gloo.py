@@ -17,7 +17,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,n", [(2, 64), (2, 61), (3, 50)])
+@pytest.mark.parametrize("world,n", [(2, 64), (2, 61), (3, 50), (3, 4)])
 def test_spmd_operator_nystrom_pcg(world, n):
     port = _free_port()
     procs = []
