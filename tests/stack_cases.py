@@ -397,3 +397,36 @@ def test_sparse_sign_sketch_structure_and_fast_apply(dev, prec):
     # right mode and small sketches keep the dense path
     skr = get_sketch("sparse", "right", 4, 50, dt, dev)
     assert skr.Omega_mat.shape == (50, 4) and int((skr.Omega_mat != 0).sum(1).max()) <= 4
+
+
+def test_linsys_callback_and_log_layout(dev, prec):
+    """User callback + log dictionary layout (models/model.py:30-52, utils/logger.py:32-47):
+    log[i] = {iter_time, cum_time, metrics: {callback, internal_metrics}}, callback called as
+    callback_fn(W, system, *args, **kwargs) on iteration 0 and every callback_freq-th iteration."""
+    dt = DTYPES[prec]
+    gen = torch.Generator().manual_seed(12)
+    n = 48
+    G = torch.randn(n, n, dtype=torch.float64, generator=gen)
+    A = (G @ G.T / n + torch.eye(n, dtype=torch.float64)).to(dt).to(dev)
+    B = torch.randn(n, 2, dtype=dt, generator=gen).to(dev)
+    seen = []
+
+    def cb(W, system, tag, scale=1.0):
+        seen.append((tuple(W.shape), system.reg, tag, scale))
+        return {"wnorm": float(W.norm()) * scale}
+
+    system = LinSys(A, B, reg=0.25)
+    rtol = 1e-9 if dt == torch.float64 else 1e-4
+    W, log = system.solve(PCGConfig(device=dev, max_iters=40, rtol=rtol), torch.zeros_like(B),
+                          callback_fn=cb, callback_args=["t"], callback_kwargs={"scale": 2.0}, callback_freq=4)
+    its = sorted(log)
+    assert its[0] == 0 and all(i % 4 == 0 for i in its) and len(seen) == len(its)
+    assert seen[0] == ((n, 2), 0.25, "t", 2.0)
+    entry = log[its[-1]]
+    assert set(entry) == {"iter_time", "cum_time", "metrics"}
+    assert set(entry["metrics"]) == {"callback", "internal_metrics"}
+    assert entry["metrics"]["callback"]["wnorm"] > 0 and entry["cum_time"] >= entry["iter_time"] >= 0
+    assert float(entry["metrics"]["internal_metrics"]["rel_res"].max()) <= rtol
+    assert system.mask.dtype == torch.bool and not bool(system.mask.any())
+    with pytest.raises(ValueError):
+        system.solve(PCGConfig(device=dev), torch.zeros_like(B), log_in_wandb=True)
