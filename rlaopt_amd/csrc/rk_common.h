@@ -48,6 +48,15 @@ struct Vec16<double> {
     static constexpr int N = 2;
 };
 
+// 16-byte load of data that is streamed exactly once (the operator): non-temporal, so that it
+// does not evict the small re-read operands (vectors, partial tables) from L2 / MALL
+template <typename V16>
+__device__ __forceinline__ V16 load_stream(const void* p) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 raw = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return __builtin_bit_cast(V16, raw);
+}
+
 // wave-wide sum (all 64 lanes end with the total)
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {

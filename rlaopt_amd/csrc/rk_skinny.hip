@@ -60,14 +60,14 @@ skinny_nn_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
         if (jb + STEP <= c_hi) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                cur[r] = *reinterpret_cast<const V16*>(arow[r] + jb + lane * VW);
+                cur[r] = load_stream<V16>(arow[r] + jb + lane * VW);
         }
         for (; jb + STEP <= c_hi; jb += STEP) {
             const int64_t j = jb + lane * VW;
             if (jb + 2 * STEP <= c_hi) {  // wave-uniform
 #pragma unroll
                 for (int r = 0; r < R; ++r)
-                    nxt[r] = *reinterpret_cast<const V16*>(arow[r] + j + STEP);
+                    nxt[r] = load_stream<V16>(arow[r] + j + STEP);
             }
             // V[j .. j+VW) x K: VW*K contiguous elements (ldv == K on this path)
             T v[VW * K];
@@ -195,7 +195,7 @@ skinny_nn_lds_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
         const int64_t j = jb + lane * VW;
         if (vecA && j + VW <= c_hi) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) dst[r] = *reinterpret_cast<const V16*>(arow[r] + j);
+            for (int r = 0; r < R; ++r) dst[r] = load_stream<V16>(arow[r] + j);
         } else {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -313,7 +313,7 @@ skinny_t_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
             V16 a[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
-                a[u] = *reinterpret_cast<const V16*>(A + (i + u) * lda + j);
+                a[u] = load_stream<V16>(A + (i + u) * lda + j);
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const T* ae = reinterpret_cast<const T*>(&a[u]);
@@ -326,7 +326,7 @@ skinny_t_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
             }
         }
         for (; i < i_hi; ++i) {
-            V16 a = *reinterpret_cast<const V16*>(A + i * lda + j);
+            V16 a = load_stream<V16>(A + i * lda + j);
             const T* ae = reinterpret_cast<const T*>(&a);
 #pragma unroll
             for (int c = 0; c < K; ++c) {

@@ -166,7 +166,7 @@ symm_strip_kernel(const TS* __restrict__ Kp, SymLayout L, const T* __restrict__ 
         for (int r = 0; r < RB; ++r) {
             int64_t i = i0 + r;
             if (i > nrows - 1) i = nrows - 1;  // clamp; contribution masked below
-            a[r] = *reinterpret_cast<const V16*>(base + i * W + lane * VW);
+            a[r] = load_stream<V16>(base + i * W + lane * VW);
 #pragma unroll
             for (int c = 0; c < K; ++c) vi[r][c] = V[i * ldv + c];  // wave-uniform address
         }

@@ -47,6 +47,17 @@ def main():
                     gb = (m * n + n * k + m * k) * es / 1e9
                     print(f"skinny {dt} m={m} n={n} k={k}: {med*1e3:.3f} ms  {gb/med:.0f} GB/s (best {gb/best:.0f})", flush=True)
                 del A
+    if "nt" in what:  # the two headline streaming kernels at bench size
+        X = torch.randn(200000, 64, device=dev) / 8
+        Kp = be.sympack_materialize("rbf", X, 1.0)
+        V = torch.randn(200000, 1, device=dev)
+        med, best = timeit(lambda: be.symm_matmat(Kp, 200000, V, diag_shift=0.1), reps=7)
+        print(f"symm n=200000 k=1: {med*1e3:.3f} ms (best {best*1e3:.3f}) {Kp.numel()*4/1e9/med:.0f} GB/s", flush=True)
+        del Kp
+        A = be.kernel_materialize("rbf", X[:25000], X, 1.0)
+        med, best = timeit(lambda: be.matmat(A, V, diag_shift=0.1), reps=7)
+        print(f"skinny 25000x200000 k=1: {med*1e3:.3f} ms (best {best*1e3:.3f}) {A.numel()*4/1e9/med:.0f} GB/s", flush=True)
+        del A
     if "tall" in what:
         for dt in (torch.float64, torch.float32):
             es = 8 if dt == torch.float64 else 4
