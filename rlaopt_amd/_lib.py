@@ -12,7 +12,8 @@ import os
 from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librk_hip.so")
+# RK_HIP_LIBRARY points at another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("RK_HIP_LIBRARY") or os.path.join(_HERE, "librk_hip.so")
 
 RK_F32, RK_F64 = 0, 1
 KIND_IDS = {"rbf": 0, "laplace": 1, "matern12": 2, "matern32": 3, "matern52": 4}

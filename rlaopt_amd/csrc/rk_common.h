@@ -89,5 +89,37 @@ __device__ __forceinline__ T wave_total_lane63(T v) {
     return v;
 }
 
+// tell the compiler a value is wave-uniform (keeps it - and what is derived from it - in SGPRs)
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+    const int lo = __builtin_amdgcn_readfirstlane((int)v);
+    const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return ((int64_t)hi << 32) | (unsigned int)lo;
+}
+
+// Streaming 16-byte load from (wave-uniform base) + (32-bit per-lane byte offset).  The base is
+// pinned in an SGPR pair and how it was computed is hidden from the optimiser, so the load is
+// selected in its saddr form: no 64-bit VGPR address temporaries (those get allocated on top of
+// in-flight load destinations and make the compiler drain the queue before every batch).
+template <typename V16>
+__device__ __forceinline__ V16 load_stream_at(const void* uniform_base, unsigned lane_off) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) char* gchar_ptr;
+    typedef const __attribute__((address_space(1))) u32x4* gvec_ptr;
+    gchar_ptr g = (gchar_ptr)uniform_base;
+    asm volatile("" : "+s"(g));
+    const u32x4 raw = __builtin_nontemporal_load((gvec_ptr)(g + lane_off));
+    return __builtin_bit_cast(V16, raw);
+}
+
+// wave-uniform copy of lane `src`'s value (src is a compile-time-uniform index): lands in SGPRs
+__device__ __forceinline__ float lane_value(float v, int src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+}
+__device__ __forceinline__ double lane_value(double v, int src) {
+    const long long bits = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane((int)bits, src);
+    const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), src);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 
 }  // namespace rk

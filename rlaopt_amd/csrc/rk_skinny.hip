@@ -35,7 +35,7 @@ skinny_nn_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
     constexpr int VW = Vec16<T>::N;
     constexpr int STEP = kWave * VW;
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // row pointers in SGPRs
     const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * R;
     if (r0 >= m) return;  // whole wave leaves; no block-level synchronisation below
     const int64_t c_lo = (int64_t)blockIdx.y * seg_cols;
@@ -56,39 +56,45 @@ skinny_nn_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
 
     int64_t jb = c_lo;
     if constexpr (VEC) {
-        V16 cur[R], nxt[R];
-        if (jb + STEP <= c_hi) {
+        // Two register stages: the loads of step jb + STEP (V slice first, then the R rows) are
+        // issued unconditionally in the same basic block that consumes step jb, so the compiler
+        // waits for the older step only (vmcnt(R + K)) instead of draining the queue.
+        V16 aA[R], aB[R], vA[K], vB[K];
+        // addresses = wave-uniform pointer (SGPR pair) + 32-bit lane offset: no per-row 64-bit
+        // VGPR address arithmetic, and no address temporaries aliasing the stage registers
+        const unsigned lane_a = (unsigned)lane * 16u, lane_v = (unsigned)lane * (16u * K);
+        auto fetch = [&](V16 a[R], V16 vv[K], int64_t jstep) {
+            // V[j .. j+VW) x K: VW*K contiguous elements (ldv == K on this path)
+            const char* vp = reinterpret_cast<const char*>(V + jstep * K) + lane_v;
+#pragma unroll
+            for (int t = 0; t < K; ++t) vv[t] = *reinterpret_cast<const V16*>(vp + 16 * t);
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                cur[r] = load_stream<V16>(arow[r] + jb + lane * VW);
-        }
-        for (; jb + STEP <= c_hi; jb += STEP) {
-            const int64_t j = jb + lane * VW;
-            if (jb + 2 * STEP <= c_hi) {  // wave-uniform
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    nxt[r] = load_stream<V16>(arow[r] + j + STEP);
-            }
-            // V[j .. j+VW) x K: VW*K contiguous elements (ldv == K on this path)
-            T v[VW * K];
-            const V16* vp = reinterpret_cast<const V16*>(V + j * K);
-#pragma unroll
-            for (int t = 0; t < K; ++t) {
-                V16 x = vp[t];
-                const T* xe = reinterpret_cast<const T*>(&x);
-#pragma unroll
-                for (int e = 0; e < VW; ++e) v[t * VW + e] = xe[e];
-            }
+                a[r] = load_stream<V16>(reinterpret_cast<const char*>(arow[r] + jstep) + lane_a);
+        };
+        auto consume = [&](const V16 a[R], const V16 vv[K]) {
+            const T* v = reinterpret_cast<const T*>(vv);  // v[q * K + c]
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const T* ae = reinterpret_cast<const T*>(&cur[r]);
+                const T* ae = reinterpret_cast<const T*>(&a[r]);
 #pragma unroll
                 for (int q = 0; q < VW; ++q)
 #pragma unroll
                     for (int c = 0; c < K; ++c) acc[r][c] += ae[q] * v[q * K + c];
             }
-#pragma unroll
-            for (int r = 0; r < R; ++r) cur[r] = nxt[r];
+        };
+        if (jb + STEP <= c_hi) {
+            fetch(aA, vA, jb);
+            for (;;) {
+                if (jb + 2 * STEP > c_hi) { consume(aA, vA); jb += STEP; break; }
+                fetch(aB, vB, jb + STEP);
+                consume(aA, vA);
+                jb += STEP;
+                if (jb + 2 * STEP > c_hi) { consume(aB, vB); jb += STEP; break; }
+                fetch(aA, vA, jb + STEP);
+                consume(aB, vB);
+                jb += STEP;
+            }
         }
     }
     // scalar path: the ragged tail of the segment, or everything when !VEC

@@ -50,7 +50,23 @@ struct SymLayout {
 template <typename T>
 constexpr int strip_width() { return kWave * Vec16<T>::N; }
 
-constexpr int ITEM_ROWS = 1024;  // rows of a strip handled by one workgroup (4 waves x 256)
+// tuning knobs (overridable at build time for experiments: tools/variants.sh + tools/ab.py)
+#ifndef RK_SYMM_ITEM_ROWS
+#define RK_SYMM_ITEM_ROWS 1024
+#endif
+#ifndef RK_SYMM_RB
+#define RK_SYMM_RB 8
+#endif
+#ifndef RK_SYMM_RB_WIDE
+#define RK_SYMM_RB_WIDE 8  // rows per batch when the per-lane accumulators are wide (K >= 2 ...)
+#endif
+#ifndef RK_SYMM_WG_PER_CU
+#define RK_SYMM_WG_PER_CU 6  // persistent grid = CUs x this (0: ask the occupancy calculator)
+#endif
+constexpr int ITEM_ROWS = RK_SYMM_ITEM_ROWS;  // rows of a strip handled by one workgroup (4 waves)
+constexpr int SYMM_THREADS = 4 * kWave;
+static_assert(ITEM_ROWS % (4 * RK_SYMM_RB) == 0, "a wave's rows must be whole batches");
+static_assert(ITEM_ROWS % 256 == 0, "items must be whole multiples of the strip widths");
 
 // ------------------------------------------------------------------------------------------
 // materialise the packed triangle
@@ -109,21 +125,34 @@ sympack_materialize_kernel(int kind, const T* __restrict__ X, int64_t ldx, int64
 // ------------------------------------------------------------------------------------------
 // TS = storage type of the packed matrix, T = type of the vectors and of all arithmetic
 // (TS = float with T = double: "fp32 storage, fp64 iteration" - fp32 HBM traffic, fp64 accuracy)
+//
+// What was measured on MI355X while tuning this kernel (tools/ab.py, n = 200000, k = 1, fp32):
+//  * with the partial-table stores removed it streams at 6.8 TB/s, the rate of the row-major
+//    kernel; the stores (0.5 % of the bytes) cost 5-8 % of the time, and the cost is not
+//    proportional to their volume (a quarter of the stores still costs 3 %), nor to which wave
+//    issues them (a dedicated writer wave changed nothing): reads and writes interleave badly
+//    at the HBM controller.  Larger per-workgroup tiles would shrink the tables, but 1 MiB
+//    items are already what the tail of a 1280-workgroup grid allows.
+//  * item order matters: ids interleaved over the persistent workgroups (the resident grid
+//    sweeps one contiguous window) beat a contiguous id range per workgroup by 1.2 % and a
+//    row-block-major order by 5 %.
+//  * real double buffering (below) and the removal of the FMA / DPP work are both within 1 %.
 template <typename TS, typename T, int K>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(SYMM_THREADS)
 symm_strip_kernel(const TS* __restrict__ Kp, SymLayout L, const T* __restrict__ V, int64_t ldv,
                   T* __restrict__ Prow, T* __restrict__ Pcol, int64_t max_items,
                   int64_t total_items) {
     using V16 = typename Vec16<TS>::type;
     constexpr int VW = Vec16<TS>::N;
     constexpr int W = strip_width<TS>();
-    constexpr int RB = 8;                     // rows per batch (loads in flight per stage)
-    constexpr int WAVE_ROWS = ITEM_ROWS / 4;  // 256
-    __shared__ T rowbuf[4][WAVE_ROWS][K];
-    __shared__ T colbuf[4][W][K];
+    // rows per batch (loads in flight per stage)
+    constexpr int RB = (VW * K * (int)sizeof(T) / 4 <= 4) ? RK_SYMM_RB : RK_SYMM_RB_WIDE;
+    __shared__ T rowbuf[ITEM_ROWS * K];
+    __shared__ T colbuf[4][W * K];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lane_off = (unsigned)lane * 16u;
     // Persistent workgroups: items (strip, 1024-row chunk) are numbered strip by strip; this
     // workgroup takes the ids blockIdx.x, blockIdx.x + gridDim.x, ... (equal-sized items, no
     // empty workgroups for the triangle's short strips).  (t, before) walks forward with the id.
@@ -136,14 +165,17 @@ symm_strip_kernel(const TS* __restrict__ Kp, SymLayout L, const T* __restrict__ 
         ++t;
     }
     const int64_t chunk = id - before;
-    const int64_t nrows = L.rows(t);
-    const int64_t item_lo = chunk * ITEM_ROWS;
+    const int64_t nrows = uniform64(L.rows(t));
+    const int64_t item_lo = uniform64(chunk * ITEM_ROWS);
+    const int64_t item_hi = item_lo + ITEM_ROWS < nrows ? item_lo + ITEM_ROWS : nrows;
     const int64_t s = L.strip(t);
-    const int64_t diag_lo = s * W;  // rows >= diag_lo belong to the (fully stored) diagonal block
-    const TS* base = Kp + L.row_offset(t) * W;
-    const int64_t r_lo = item_lo + (int64_t)wave * WAVE_ROWS;
-    int64_t r_hi = r_lo + WAVE_ROWS;
-    if (r_hi > nrows) r_hi = nrows;
+    const int64_t diag_lo = uniform64(s * W);  // rows >= diag_lo: the (fully stored) diagonal block
+    const TS* base = Kp + uniform64(L.row_offset(t) * W);  // (offset, not the pointer: keeps it global)
+    // the item's batches of RB rows (8 KiB each) are dealt round-robin to the 4 waves: the
+    // workgroup sweeps its item front to back as one 4-batch-wide window
+    const int nb_item = (int)((item_hi - item_lo + RB - 1) / RB);
+    const int nbw = wave < nb_item ? (nb_item - wave + 3) / 4 : 0;
+    auto batch_of = [&](int b) -> int { return b * 4 + wave; };
 
     // this lane's VW columns of the strip and their right-hand-side entries
     T vj[VW][K];
@@ -159,26 +191,36 @@ symm_strip_kernel(const TS* __restrict__ Kp, SymLayout L, const T* __restrict__ 
 #pragma unroll
         for (int c = 0; c < K; ++c) col[q][c] = T(0);
 
-    V16 cur[RB], nxt[RB];
-    T vcur[RB][K], vnxt[RB][K];
-    auto fetch = [&](V16 a[RB], T vi[RB][K], int64_t i0) {
+    // Two register stages (A, B): while one batch is consumed from one stage the loads of the
+    // wave's next batch are already in flight into the other.  The fetch is unconditional inside
+    // its basic block, so the compiler waits for the older batch only instead of draining the
+    // queue.  V[i] of the batch rides in one vector load (lane r*K + c holds V[i0 + r][c]; read
+    // back with readlane), keeping every wait on the in-order vmcnt counter.
+    V16 stA[RB], stB[RB];
+    T vA, vB;
+    auto fetch = [&](V16 a[RB], T& vi, int b) {
+        const int64_t i0 = item_lo + (int64_t)batch_of(b) * RB;
+        {   // every lane loads (lanes >= RB*K repeat the last entry): no divergent branch
+            const int e = lane < RB * K ? lane : RB * K - 1;
+            int64_t i = i0 + e / K;
+            if (i > nrows - 1) i = nrows - 1;
+            vi = V[i * ldv + e % K];
+        }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             int64_t i = i0 + r;
             if (i > nrows - 1) i = nrows - 1;  // clamp; contribution masked below
-            a[r] = load_stream<V16>(base + i * W + lane * VW);
-#pragma unroll
-            for (int c = 0; c < K; ++c) vi[r][c] = V[i * ldv + c];  // wave-uniform address
+            a[r] = load_stream_at<V16>(base + i * W, lane_off);
         }
     };
-    if (r_lo < r_hi) fetch(cur, vcur, r_lo);
-    for (int64_t i0 = r_lo; i0 < r_hi; i0 += RB) {
-        if (i0 + RB < r_hi) fetch(nxt, vnxt, i0 + RB);
-        const bool above = i0 < diag_lo;  // batch-uniform: diag_lo and i0 are multiples of 8
+    auto consume = [&](const V16 a[RB], T vi, int b) {
+        const int pb = batch_of(b);
+        const int64_t i0 = item_lo + (int64_t)pb * RB;
+        const bool above = i0 < diag_lo;  // batch-uniform: diag_lo and i0 are multiples of RB
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            const bool live = i0 + r < r_hi;
-            const TS* as = reinterpret_cast<const TS*>(&cur[r]);
+            const bool live = i0 + r < item_hi;
+            const TS* as = reinterpret_cast<const TS*>(&a[r]);
             T ae[VW];
 #pragma unroll
             for (int q = 0; q < VW; ++q) ae[q] = (T)as[q];
@@ -191,38 +233,45 @@ symm_strip_kernel(const TS* __restrict__ Kp, SymLayout L, const T* __restrict__ 
                 for (int c = 0; c < K; ++c) dot[c] += ae[q] * vj[q][c];
             if (above && live) {
 #pragma unroll
-                for (int q = 0; q < VW; ++q)
+                for (int c = 0; c < K; ++c) {
+                    const T vic = lane_value(vi, r * K + c);
 #pragma unroll
-                    for (int c = 0; c < K; ++c) col[q][c] += ae[q] * vcur[r][c];
+                    for (int q = 0; q < VW; ++q) col[q][c] += ae[q] * vic;
+                }
             }
 #pragma unroll
             for (int c = 0; c < K; ++c) {
                 const T tot = wave_total_lane63(dot[c]);
-                if (lane == 63 && live) rowbuf[wave][i0 - r_lo + r][c] = tot;
+                if (lane == 63 && live) rowbuf[(pb * RB + r) * K + c] = tot;
             }
         }
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            cur[r] = nxt[r];
-#pragma unroll
-            for (int c = 0; c < K; ++c) vcur[r][c] = vnxt[r][c];
+    };
+    if (nbw > 0) {
+        int b = 0;
+        fetch(stA, vA, b);
+        for (;;) {
+            if (b + 1 >= nbw) { consume(stA, vA, b); break; }
+            fetch(stB, vB, b + 1);
+            consume(stA, vA, b);
+            ++b;
+            if (b + 1 >= nbw) { consume(stB, vB, b); break; }
+            fetch(stA, vA, b + 1);
+            consume(stB, vB, b);
+            ++b;
         }
     }
-    // row sums of this wave's rows -> Prow, coalesced
 #pragma unroll
     for (int q = 0; q < VW; ++q)
 #pragma unroll
-        for (int c = 0; c < K; ++c) colbuf[wave][lane * VW + q][c] = col[q][c];
+        for (int c = 0; c < K; ++c) colbuf[wave][(lane * VW + q) * K + c] = col[q][c];
     __syncthreads();  // rowbuf (written by lane 63) and colbuf are complete
-    const int64_t prow0 = L.row_offset(t) + r_lo;
-    for (int e = lane; e < (int)(r_hi > r_lo ? (r_hi - r_lo) : 0) * K; e += 64)
-        Prow[prow0 * K + e] = rowbuf[wave][e / K][e % K];
+    // row sums of the item's rows -> Prow, coalesced
+    T* pr = Prow + (L.row_offset(t) + item_lo) * K;
+    for (int e = threadIdx.x; e < (int)(item_hi - item_lo) * K; e += SYMM_THREADS) pr[e] = rowbuf[e];
     // column sums of the 4 waves -> Pcol[item]
     T* pc = Pcol + ((t * max_items + chunk) * W) * K;
-    for (int e = threadIdx.x; e < W * K; e += 256) {
-        const int j = e / K, c = e - j * K;
-        pc[e] = ((colbuf[0][j][c] + colbuf[1][j][c]) + colbuf[2][j][c]) + colbuf[3][j][c];
-    }
+    for (int e = threadIdx.x; e < W * K; e += SYMM_THREADS)
+        pc[e] = ((colbuf[0][e] + colbuf[1][e]) + colbuf[2][e]) + colbuf[3][e];
     __syncthreads();  // rowbuf / colbuf are reused by the next item
   }
 }
@@ -309,9 +358,27 @@ template <typename TS, typename T>
 static size_t symm_ws_bytes(int64_t n, int64_t k, int64_t first, int64_t stride) {
     const SymLayout L = make_layout<TS>(n, first, stride);
     const int64_t max_items = ceil_div(n, ITEM_ROWS);
-    const size_t prow = (size_t)L.total_rows() * k;
+    const size_t prow = (size_t)round_up(L.total_rows() * k, 16);  // keeps Pcol 16-byte aligned
     const size_t pcol = (size_t)L.strips_local() * max_items * L.W * k;
     return (prow + pcol) * sizeof(T);
+}
+
+// resident workgroups of the persistent strip kernel on this device (cached per instantiation)
+template <typename KernelT>
+static int64_t symm_resident_workgroups(KernelT kernel) {
+    static int64_t cached = 0;
+    if (cached == 0) {
+        int per_cu = RK_SYMM_WG_PER_CU, dev = 0, cus = 0;
+        if (per_cu <= 0 &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, SYMM_THREADS, 0) != hipSuccess)
+            per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            cus = 0;
+        (void)hipGetLastError();
+        cached = (int64_t)(per_cu > 0 ? per_cu : 3) * (cus > 0 ? cus : 256);
+    }
+    return cached;
 }
 
 template <typename TS, typename T>
@@ -327,15 +394,17 @@ static int symm_matmat_impl(const TS* Kp, int64_t n, int64_t first, int64_t stri
         return RK_ERR_WORKSPACE;
     }
     T* Prow = static_cast<T*>(ws);
-    T* Pcol = Prow + (size_t)L.total_rows() * k;
+    T* Pcol = Prow + (size_t)round_up(L.total_rows() * k, 16);
     if (T_loc > 0) {
         int64_t total_items = 0;
         for (int64_t t = 0; t < T_loc; ++t) total_items += ceil_div(L.rows(t), ITEM_ROWS);
-        const int64_t resident = 256 * 6;  // CUs x workgroups per CU
-        dim3 grid((unsigned)(total_items < resident ? total_items : resident));
 #define RK_SYMM(KK)                                                                             \
-    hipLaunchKernelGGL((symm_strip_kernel<TS, T, KK>), grid, dim3(256), 0, st, Kp, L, V, ldv, Prow, \
-                       Pcol, max_items, total_items)
+    {                                                                                           \
+        const int64_t resident = symm_resident_workgroups(symm_strip_kernel<TS, T, KK>);        \
+        dim3 grid((unsigned)(total_items < resident ? total_items : resident));                 \
+        hipLaunchKernelGGL((symm_strip_kernel<TS, T, KK>), grid, dim3(SYMM_THREADS), 0, st, Kp, L, V, \
+                           ldv, Prow, Pcol, max_items, total_items);                            \
+    }
         switch (k) {
             case 1: RK_SYMM(1); break;
             case 2: RK_SYMM(2); break;
@@ -420,6 +489,7 @@ extern "C" int rk_symm_matmat(int dtype, int store_dtype, const void* Kp, int64_
     RK_REQUIRE(k >= 1 && k <= 4, "rk_symm_matmat: k=%lld outside [1,4]", (long long)k);
     RK_REQUIRE(ldv >= k && ldy >= k, "rk_symm_matmat: leading dimension too small");
     RK_REQUIRE(aligned16(Kp), "rk_symm_matmat: packed matrix must be 16-byte aligned");
+    RK_REQUIRE(aligned16(ws), "rk_symm_matmat: workspace must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == RK_F32)
         return symm_matmat_impl<float, float>((const float*)Kp, n, strip_first, strip_stride,

@@ -47,6 +47,31 @@ def main():
                     gb = (m * n + n * k + m * k) * es / 1e9
                     print(f"skinny {dt} m={m} n={n} k={k}: {med*1e3:.3f} ms  {gb/med:.0f} GB/s (best {gb/best:.0f})", flush=True)
                 del A
+    if "symm1" in what:  # the headline kernel only (tuning variants)
+        X = torch.randn(200000, 64, device=dev) / 8
+        Kp = be.sympack_materialize("rbf", X, 1.0)
+        V = torch.randn(200000, 1, device=dev)
+        med, best = timeit(lambda: be.symm_matmat(Kp, 200000, V, diag_shift=0.1), reps=9)
+        print(f"symm n=200000 k=1: {med*1e3:.3f} ms (best {best*1e3:.3f}) {Kp.numel()*4/1e9/med:.0f} GB/s", flush=True)
+        del Kp
+    if "foot" in what:  # does the streaming rate depend on the footprint? (20 / 40 / 80 GB)
+        V = torch.randn(200000, 1, device=dev)
+        for rows in (25000, 50000, 100000):
+            A = torch.empty(rows, 200000, device=dev)
+            A.normal_()
+            med, best = timeit(lambda: be.matmat(A, V, diag_shift=0.1), reps=7)
+            print(f"skinny {rows}x200000 k=1: {med*1e3:.3f} ms (best {best*1e3:.3f}) {A.numel()*4/1e9/med:.0f} GB/s", flush=True)
+            del A
+    if "shape" in what:  # one 40 GB buffer streamed as matrices of different row lengths
+        buf = torch.empty(10_000_000_000, device=dev)
+        buf.normal_()
+        for cols in (256, 1024, 8192, 65536, 200000):
+            rows = buf.numel() // cols
+            A = buf[: rows * cols].view(rows, cols)
+            V = torch.randn(cols, 1, device=dev)
+            med, best = timeit(lambda: be.matmat(A, V), reps=5)
+            print(f"skinny {rows}x{cols} k=1: {med*1e3:.3f} ms (best {best*1e3:.3f}) {A.numel()*4/1e9/med:.0f} GB/s", flush=True)
+        del buf, A
     if "nt" in what:  # the two headline streaming kernels at bench size
         X = torch.randn(200000, 64, device=dev) / 8
         Kp = be.sympack_materialize("rbf", X, 1.0)

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Build tuning variants of librk_hip.so into build_var/<name>/librk_hip.so:
+#   tools/variants.sh name1 "-DRK_SYMM_ITEM_ROWS=2048" name2 "-DRK_SYMM_RB=4" ...
+# run one with RK_HIP_LIBRARY=build_var/<name>/librk_hip.so python tools/microbench.py --what nt
+set -e
+cd "$(dirname "$0")/.."
+SRC=rlaopt_amd/csrc
+while [ $# -ge 2 ]; do
+  name=$1; flags=$2; shift 2
+  out=build_var/$name; mkdir -p $out
+  objs=""
+  for f in rk_skinny.hip rk_kernelmat.hip rk_gemm.hip rk_symm.hip rk_api.cpp; do
+    o=$out/${f%.*}.o
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-slp-vectorize $flags -x hip -c $SRC/$f -o $o &
+    objs="$objs $o"
+  done
+  wait
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $out/librk_hip.so
+  rm -f $objs
+  echo "built $out/librk_hip.so ($flags)"
+done
