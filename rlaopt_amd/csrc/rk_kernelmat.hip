@@ -175,13 +175,255 @@ kmat_matmat_finish(const T* __restrict__ part, int S, int64_t n1, int k, T scale
     else Y[i * ldy + c] = s;
 }
 
+// ------------------------------------------------------------------------------------------
+// fused product, float32: 64 x 128 tile, 4 x 8 pairs per lane, packed fp32 math
+// ------------------------------------------------------------------------------------------
+// The 4 x 4 tile above spends two VALU instructions (sub, fma) and 2/16 of a ds_read_b128 per
+// pair and feature.  Here every instruction is a v_pk_add_f32 / v_pk_fma_f32 working on two
+// pairs, and a lane owns 4 rows x (4 + 4) columns (columns tx*4.. and 64 + tx*4.., so that both
+// panel reads stay conflict-free 16-byte accesses): 1 VALU instruction and 3/32 of a
+// ds_read_b128 per pair and feature.  The V slice sits rhs-major in LDS (vs[c][column]) so that
+// the 16 lanes of a row read 16 consecutive float4 (the point-major layout of the 4 x 4 kernel
+// is a 16-way bank conflict for KB = 16), and the y update is packed over row pairs.  The 16
+// lanes that share a row are one DPP row: their sums combine with 4 v_add_f32_dpp, no LDS.
+constexpr int TNW = 128;   // tile columns of the wide kernel
+constexpr int LDPW = 132;  // padded stride of its column panel
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Stage NP points x DCV features (chunk c0) into LDS feature-major, coalesced: a point's chunk
+// is contiguous in the row-major X, so lanes are laid along the features (VLD floats per lane,
+// 32 / VLD lanes per point) and a wave instruction touches 8 - 16 cache lines; the point-per-lane
+// gather of stage_panel touches 64 and was as expensive as the tile arithmetic.  VLD = 4 / 2 / 1
+// by the alignment of the rows (d = 50 rows are only 8-byte aligned).
+template <int NP, int DCV, int LD, int VLD>
+__device__ __forceinline__ void stage_panel_f32(float (*dst)[LD], int off,
+                                                const float* __restrict__ X, int64_t n, int64_t ldx,
+                                                const int64_t* __restrict__ idx, int64_t p0,
+                                                int64_t c0, int64_t d,
+                                                const float* __restrict__ ell_vec) {
+    constexpr int LPP = DCV / VLD;       // lanes per point
+    constexpr int PPP = 256 / LPP;       // points per pass of the workgroup
+    const int f = (threadIdx.x % LPP) * VLD;
+    const int pl = threadIdx.x / LPP;
+#pragma unroll
+    for (int u = 0; u < NP / PPP; ++u) {
+        const int pt = pl + u * PPP;
+        const int64_t p = p0 + pt;
+        float v[VLD];
+#pragma unroll
+        for (int e = 0; e < VLD; ++e) v[e] = 0.f;
+        if (p < n) {
+            const float* src = X + (idx ? idx[p] : p) * ldx + c0 + f;
+            if (c0 + f + VLD <= d) {
+                if constexpr (VLD == 4) {
+                    const float4 x = *reinterpret_cast<const float4*>(src);
+                    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+                } else if constexpr (VLD == 2) {
+                    const float2 x = *reinterpret_cast<const float2*>(src);
+                    v[0] = x.x; v[1] = x.y;
+                } else {
+                    v[0] = src[0];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VLD; ++e)
+                    if (c0 + f + e < d) v[e] = src[e];
+            }
+            if (ell_vec) {
+#pragma unroll
+                for (int e = 0; e < VLD; ++e)
+                    if (c0 + f + e < d) v[e] = v[e] / ell_vec[c0 + f + e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VLD; ++e) dst[f + e][off + pt] = v[e];
+    }
+}
+
+// point-per-lane staging (any alignment): lane -> point, wave -> DCV/4 consecutive features
+template <int DCV, int LD>
+__device__ __forceinline__ void stage_panel_pt_f32(float (*dst)[LD], int off,
+                                                   const float* __restrict__ X, int64_t n,
+                                                   int64_t ldx, const int64_t* __restrict__ idx,
+                                                   int64_t p0, int64_t c0, int64_t d,
+                                                   const float* __restrict__ ell_vec) {
+    const int pt = threadIdx.x & 63;
+    const int cg = threadIdx.x >> 6;  // 0..3
+    const int64_t p = p0 + pt;
+    const float* row = nullptr;
+    if (p < n) row = X + (idx ? idx[p] : p) * ldx;
+#pragma unroll
+    for (int u = 0; u < DCV / 4; ++u) {
+        const int c = cg * (DCV / 4) + u;
+        float v = 0.f;
+        if (row != nullptr && c0 + c < d) {
+            v = row[c0 + c];
+            if (ell_vec) v = v / ell_vec[c0 + c];
+        }
+        dst[c][off + pt] = v;
+    }
+}
+
+__device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes of a DPP row
+    v += dpp_fetch<0xB1, 0xF>(v);
+    v += dpp_fetch<0x4E, 0xF>(v);
+    v += dpp_fetch<0x141, 0xF>(v);
+    v += dpp_fetch<0x140, 0xF>(v);
+    return v;
+}
+
+template <bool L1, int KB, int VLD, int DCV>
+__global__ void __launch_bounds__(256)
+kmat_matmat_wide_kernel(int kind, const float* __restrict__ X1, int64_t n1, int64_t ldx1,
+                        const int64_t* __restrict__ idx1, const float* __restrict__ X2, int64_t n2,
+                        int64_t ldx2, const int64_t* __restrict__ idx2, int64_t d, float w,
+                        const float* __restrict__ ell_vec, float scale, const float* __restrict__ V,
+                        int k, int64_t ldv, int64_t tiles_per_seg, float* __restrict__ part,
+                        float* __restrict__ Y, int64_t ldy, int accumulate) {
+    __shared__ __attribute__((aligned(16))) float xs[DCV][LDP];
+    __shared__ __attribute__((aligned(16))) float ys[DCV][LDPW];
+    __shared__ __attribute__((aligned(16))) float vs[KB][LDPW];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int64_t i0 = (int64_t)blockIdx.x * TM;
+    const int64_t ntile = (n2 + TNW - 1) / TNW;
+    const int64_t t_lo = (int64_t)blockIdx.y * tiles_per_seg;
+    const int64_t t_hi = (t_lo + tiles_per_seg < ntile) ? t_lo + tiles_per_seg : ntile;
+
+    // y2[h][c] = running sums of rows (2h, 2h + 1) for right-hand side c
+    f32x2 y2[2][KB];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int c = 0; c < KB; ++c) y2[h][c] = (f32x2)(0.f);
+
+    const bool one_chunk = (d <= DCV);
+    auto stage_x = [&](int64_t c0) {
+        if constexpr (VLD == 0) stage_panel_pt_f32<DCV, LDP>(xs, 0, X1, n1, ldx1, idx1, i0, c0, d, ell_vec);
+        else stage_panel_f32<TM, DCV, LDP, VLD>(xs, 0, X1, n1, ldx1, idx1, i0, c0, d, ell_vec);
+    };
+    auto stage_y = [&](int64_t j0, int64_t c0) {
+        if constexpr (VLD == 0) {
+            stage_panel_pt_f32<DCV, LDPW>(ys, 0, X2, n2, ldx2, idx2, j0, c0, d, ell_vec);
+            stage_panel_pt_f32<DCV, LDPW>(ys, 64, X2, n2, ldx2, idx2, j0 + 64, c0, d, ell_vec);
+        } else {
+            stage_panel_f32<TNW, DCV, LDPW, VLD>(ys, 0, X2, n2, ldx2, idx2, j0, c0, d, ell_vec);
+        }
+    };
+    if (one_chunk) stage_x(0);
+    for (int64_t t = t_lo; t < t_hi; ++t) {
+        const int64_t j0 = t * TNW;
+        // acc[r][g][h]: row r, column group g (tx*4.. / 64 + tx*4..), columns (2h, 2h + 1) of it
+        f32x2 acc[4][2][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) acc[r][g][h] = (f32x2)(0.f);
+        for (int64_t c0 = 0; c0 < d; c0 += DCV) {
+            __syncthreads();  // readers of the previous panels / V slice are done
+            if (!one_chunk) stage_x(c0);
+            stage_y(j0, c0);
+            if (c0 == 0) {
+                // V slice of this column tile, rhs-major, zero padded to KB columns / past n2
+                for (int e = threadIdx.x; e < TNW * KB; e += 256) {
+                    const int jj = e / KB, c = e - jj * KB;
+                    const int64_t j = j0 + jj;
+                    vs[c][jj] = (j < n2 && c < k) ? V[j * ldv + c] : 0.f;
+                }
+            }
+            __syncthreads();
+            const int nc = (int)((d - c0) < DCV ? (d - c0) : DCV);
+            // operands of feature c + 1 are fetched from LDS while feature c is being used
+            float4 xa = *reinterpret_cast<const float4*>(&xs[0][ty * 4]);
+            float4 ya = *reinterpret_cast<const float4*>(&ys[0][tx * 4]);
+            float4 yb = *reinterpret_cast<const float4*>(&ys[0][64 + tx * 4]);
+            auto step = [&](int c) {
+                const int cn = c + 1 < DCV ? c + 1 : DCV - 1;  // (stays inside the panel)
+                const float4 xa_n = *reinterpret_cast<const float4*>(&xs[cn][ty * 4]);
+                const float4 ya_n = *reinterpret_cast<const float4*>(&ys[cn][tx * 4]);
+                const float4 yb_n = *reinterpret_cast<const float4*>(&ys[cn][64 + tx * 4]);
+                const f32x2 yv[2][2] = {{{ya.x, ya.y}, {ya.z, ya.w}}, {{yb.x, yb.y}, {yb.z, yb.w}}};
+                const float xr[4] = {xa.x, xa.y, xa.z, xa.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const f32x2 xv = (f32x2)(xr[r]);
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const f32x2 df = xv - yv[g][h];
+                            if constexpr (L1) acc[r][g][h] += __builtin_elementwise_abs(df);
+                            else acc[r][g][h] = __builtin_elementwise_fma(df, df, acc[r][g][h]);
+                        }
+                }
+                xa = xa_n; ya = ya_n; yb = yb_n;
+            };
+            if (nc == DCV) {
+#pragma unroll 4
+                for (int c = 0; c < DCV; ++c) step(c);
+            } else {
+#pragma unroll 2
+                for (int c = 0; c < nc; ++c) step(c);
+            }
+        }
+        // kernel values, packed over row pairs: kv[g][q][h] = (K[2h][col], K[2h+1][col])
+        f32x2 kv[2][4][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float a = kernel_value<float>(kind, acc[2 * h][g][q >> 1][q & 1], w);
+                    const float b = kernel_value<float>(kind, acc[2 * h + 1][g][q >> 1][q & 1], w);
+                    kv[g][q][h] = (f32x2){a, b};
+                }
+#pragma unroll
+        for (int c = 0; c < KB; ++c) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                // zero entries past n2 kill padded pairs
+                const float4 v4 = *reinterpret_cast<const float4*>(&vs[c][g * 64 + tx * 4]);
+                const float vq[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x2 vv = (f32x2)(vq[q]);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        y2[h][c] = __builtin_elementwise_fma(kv[g][q][h], vv, y2[h][c]);
+                }
+            }
+        }
+    }
+    // combine the 16 lanes (tx) that share each row: they form one DPP row
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = i0 + ty * 4 + r;
+#pragma unroll
+        for (int c = 0; c < KB; ++c) {
+            const float sum = row16_sum(y2[r >> 1][c][r & 1]);
+            if (tx == 0 && i < n1 && c < k) {
+                if (part != nullptr) {
+                    part[((int64_t)blockIdx.y * n1 + i) * k + c] = sum;
+                } else {
+                    const float o = scale * sum;
+                    if (accumulate) Y[i * ldy + c] += o;
+                    else Y[i * ldy + c] = o;
+                }
+            }
+        }
+    }
+}
+
 struct KMPlan {
     int64_t S, tiles_per_seg;
 };
 
-static KMPlan plan_kmatmat(int64_t n1, int64_t n2) {
+static KMPlan plan_kmatmat(int64_t n1, int64_t n2, int tile_cols = TN) {
     const int64_t row_blocks = ceil_div(n1, TM);
-    const int64_t ntile = ceil_div(n2, TN);
+    const int64_t ntile = ceil_div(n2, tile_cols);
     int64_t S = ceil_div(4096, row_blocks);  // >= ~16 workgroups per CU in flight
     if (S > ntile / 8) S = ntile / 8;        // >= 8 column tiles per workgroup
     if (S < 1) S = 1;
@@ -237,6 +479,66 @@ static void launch_kmatmat(int KB, dim3 grid, hipStream_t st, int kind, const T*
 #undef RK_KM
 }
 
+#ifndef RK_KMAT_WIDE
+#define RK_KMAT_WIDE 1
+#endif
+#ifndef RK_KMAT_COAL_MIN
+#define RK_KMAT_COAL_MIN 4  // coalesced staging only for 16-byte aligned rows (measured)
+#endif
+#ifndef RK_KMAT_WIDE_DCV64
+#define RK_KMAT_WIDE_DCV64 1
+#endif
+// column-tile width of the fused product: the packed 64 x 128 kernel for float32
+static int kmat_tile_cols(bool is_f32, int64_t d) {
+    return (is_f32 && RK_KMAT_WIDE && d > 40) ? TNW : TN;  // short rows: the 4 x 4 kernel is faster
+}
+
+template <bool L1>
+static void launch_kmatmat_wide(int KB, dim3 grid, hipStream_t st, int kind, const float* X1,
+                                int64_t n1, int64_t ldx1, const int64_t* idx1, const float* X2,
+                                int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d, float w,
+                                const float* ell_vec, float scale, const float* V, int k,
+                                int64_t ldv, int64_t tps, float* part, float* Y, int64_t ldy,
+                                int accumulate) {
+    // widest aligned load of a row chunk (chunks start at multiples of 32 features)
+    auto row_align = [](const float* X, int64_t ldx) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(X);
+        if (a % 16 == 0 && ldx % 4 == 0) return 4;
+        if (a % 8 == 0 && ldx % 2 == 0) return 2;
+        return 1;
+    };
+    const int v1 = row_align(X1, ldx1), v2 = row_align(X2, ldx2);
+    int vld = v1 < v2 ? v1 : v2;
+    if (vld < RK_KMAT_COAL_MIN) vld = 0;  // point-per-lane staging
+    // one staged chunk holds 32 features (d <= 32) or 64 (fewer barriers and stagings per tile)
+    const bool dc64 = RK_KMAT_WIDE_DCV64 && d > 32;
+#define RK_KMW_D(KBV, VLDV, DCVV)                                                                 \
+    hipLaunchKernelGGL((kmat_matmat_wide_kernel<L1, KBV, VLDV, DCVV>), grid, dim3(256), 0, st, kind, \
+                       X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d, w, ell_vec, scale, V, k, ldv,    \
+                       tps, part, Y, ldy, accumulate)
+#define RK_KMW_V(KBV, VLDV)                                                                       \
+    do {                                                                                          \
+        if (dc64) RK_KMW_D(KBV, VLDV, 64);                                                        \
+        else RK_KMW_D(KBV, VLDV, 32);                                                             \
+    } while (0)
+#define RK_KMW(KBV)                                                                               \
+    do {                                                                                          \
+        if (vld == 4) RK_KMW_V(KBV, 4);                                                           \
+        else if (vld == 2) RK_KMW_V(KBV, 2);                                                      \
+        else RK_KMW_V(KBV, 0);                                                                    \
+    } while (0)
+    switch (KB) {
+        case 1: RK_KMW(1); break;
+        case 2: RK_KMW(2); break;
+        case 4: RK_KMW(4); break;
+        case 8: RK_KMW(8); break;
+        default: RK_KMW(16); break;
+    }
+#undef RK_KMW
+#undef RK_KMW_V
+#undef RK_KMW_D
+}
+
 template <typename T>
 static int kmatmat_impl(int kind, const T* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
                         const T* X2, int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d,
@@ -244,7 +546,7 @@ static int kmatmat_impl(int kind, const T* X1, int64_t n1, int64_t ldx1, const i
                         int64_t ldv, T* Y, int64_t ldy, int accumulate, void* ws, size_t ws_bytes,
                         hipStream_t st) {
     const T w = ell_vec ? T(1) : T(1.0 / ell);
-    const KMPlan p = plan_kmatmat(n1, n2);
+    const KMPlan p = plan_kmatmat(n1, n2, kmat_tile_cols(sizeof(T) == 4, d));
     T* part = nullptr;
     if (p.S > 1) {
         const size_t need = (size_t)p.S * n1 * k * sizeof(T);
@@ -256,6 +558,23 @@ static int kmatmat_impl(int kind, const T* X1, int64_t n1, int64_t ldx1, const i
     }
     const int KB = k <= 1 ? 1 : (k <= 2 ? 2 : (k <= 4 ? 4 : (k <= 8 ? 8 : 16)));
     dim3 grid((unsigned)ceil_div(n1, TM), (unsigned)p.S);
+    if constexpr (sizeof(T) == 4) {
+        if (kmat_tile_cols(true, d) == TNW) {
+            if (kind == RK_LAPLACE)
+                launch_kmatmat_wide<true>(KB, grid, st, kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d,
+                                          w, ell_vec, (T)scale, V, (int)k, ldv, p.tiles_per_seg, part,
+                                          Y, ldy, accumulate);
+            else
+                launch_kmatmat_wide<false>(KB, grid, st, kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d,
+                                           w, ell_vec, (T)scale, V, (int)k, ldv, p.tiles_per_seg, part,
+                                           Y, ldy, accumulate);
+            int rcw = launch_status("rk_kernel_matmat");
+            if (rcw != RK_OK || part == nullptr) return rcw;
+            hipLaunchKernelGGL((kmat_matmat_finish<T>), dim3((unsigned)ceil_div(n1 * k, 256)), dim3(256),
+                               0, st, part, (int)p.S, n1, (int)k, (T)scale, Y, ldy, accumulate);
+            return launch_status("rk_kernel_matmat(finish)");
+        }
+    }
     if (kind == RK_LAPLACE)
         launch_kmatmat<T, true>(KB, grid, st, kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d, w,
                                 ell_vec, (T)scale, V, (int)k, ldv, p.tiles_per_seg, part, Y, ldy,
@@ -311,8 +630,10 @@ extern "C" int rk_kernel_materialize(int dtype, int kind, const void* X1, int64_
 
 extern "C" size_t rk_kernel_matmat_ws_bytes(int dtype, int64_t n1, int64_t n2, int64_t k) {
     if (n1 <= 0 || n2 <= 0 || k <= 0 || k > 16) return 0;
-    const KMPlan p = plan_kmatmat(n1, n2);
-    return p.S > 1 ? (size_t)p.S * n1 * k * (dtype == RK_F32 ? 4 : 8) : 0;
+    // the tile shape depends on d (not an argument here): size for the larger of the two plans
+    const KMPlan pa = plan_kmatmat(n1, n2, TN), pb = plan_kmatmat(n1, n2, TNW);
+    const int64_t S = pa.S > pb.S ? pa.S : pb.S;
+    return S > 1 ? (size_t)S * n1 * k * (dtype == RK_F32 ? 4 : 8) : 0;
 }
 
 extern "C" int rk_kernel_matmat(int dtype, int kind, const void* X1, int64_t n1, int64_t ldx1,

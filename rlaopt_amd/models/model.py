@@ -8,7 +8,7 @@ from warnings import warn
 import torch
 
 from ..solvers import Solver, SolverConfig
-from ..utils import Logger
+from ..utils import Logger, quiet_host
 
 __all__ = ["Model"]
 
@@ -63,18 +63,19 @@ class Model(ABC):
         """Iteration 0 and every ``log_freq``-th iteration are logged; termination is tested
         only on logged iterations, so reported iteration counts are multiples of
         ``callback_freq``."""
-        log = {0: logger._compute_log(0, solver.W)}
-        if termination_fn(log[0]["metrics"]["internal_metrics"]):
+        with quiet_host():  # no spinning CPU workers next to a loop that syncs with the device
+            log = {0: logger._compute_log(0, solver.W)}
+            if termination_fn(log[0]["metrics"]["internal_metrics"]):
+                return solver.W, log
+            for i in range(1, max_iters + 1):
+                solver._step()
+                entry = logger._compute_log(i, solver.W) if i % logger.log_freq == 0 else None
+                if entry is not None:
+                    log[i] = entry
+                    if termination_fn(entry["metrics"]["internal_metrics"]):
+                        break
+            logger._terminate()
             return solver.W, log
-        for i in range(1, max_iters + 1):
-            solver._step()
-            entry = logger._compute_log(i, solver.W) if i % logger.log_freq == 0 else None
-            if entry is not None:
-                log[i] = entry
-                if termination_fn(entry["metrics"]["internal_metrics"]):
-                    break
-        logger._terminate()
-        return solver.W, log
 
     @abstractmethod
     def solve(self, solver_config: SolverConfig, W_init: torch.Tensor, callback_fn=None,

@@ -13,6 +13,7 @@ Not reproduced: the reference's ``UnboundLocalError`` for NewtonConfig with rho 
 
 from __future__ import annotations
 
+import os
 from typing import TYPE_CHECKING
 
 import torch
@@ -24,6 +25,7 @@ from ..preconditioners import (
 )
 from ..preconditioners import _get_precond as _pf_get_precond
 from ..spectral_estimators import randomized_powering
+from ..utils import quiet_host
 from .configs import SAPAccelConfig
 from .solver import Solver
 
@@ -50,6 +52,8 @@ class SAP(Solver):
         self.power_iters = power_iters
         n = system.A.shape[0]
         self.probs = torch.ones(n) / n
+        self._side = None     # lazily created side stream (see _step)
+        self._overlap = os.environ.get("RK_SAP_OVERLAP", "1") != "0"
         self._blocks = None   # optional injected block sequence (parity runs)
         self._starts = None   # optional injected power-iteration start vectors
         if accel:
@@ -104,22 +108,54 @@ class SAP(Solver):
         max_eig, _ = randomized_powering(S, max_iters=self.power_iters, v0=v0)
         return float(max_eig) ** -1.0
 
+    def _side_stream(self):
+        """Second HIP stream for the block gradient (single-process GPU runs only: in an SPMD run
+        the row-oracle product contains a collective, which stays in program order)."""
+        if not self._W.is_cuda or _dist.spmd_active() or not self._overlap:
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self._W.device)
+        return self._side
+
+    def _block_gradient(self, W, B, blk):
+        return self.system.A_row_oracle(blk) @ W + self.system.reg * W[blk, :] - B[blk, :]
+
     def _get_block_update(self, W, B, blk, blk_precond):
-        grad = self.system.A_row_oracle(blk) @ W + self.system.reg * W[blk, :] - B[blk, :]
-        return blk_precond._inv @ grad
+        return blk_precond._inv @ self._block_gradient(W, B, blk)
 
     def _step(self):
+        with quiet_host():
+            self._step_impl()
+
+    def _step_impl(self):
         mask = self.system.mask
         if not bool(mask.any()):
             return
         cols = torch.nonzero(mask)[:, 0].to(self._W.device)
         blk = self._get_blk()
-        blk_precond = self._get_precond(blk)
-        eta = self._get_stepsize(blk, blk_precond)
         blk_d = blk.to(self._W.device)
         base = self.Y if self.accel else self._W
         loc = base[:, cols]
-        d = self._get_block_update(loc, self.system.B[:, cols], blk_d, blk_precond)
+        # The block gradient (the blk x n row-oracle product: 2/3 of the iteration) depends on
+        # neither the block preconditioner nor the step size.  On a GPU it is queued first, on a
+        # side stream, so that it overlaps the preconditioner assembly and the power iteration -
+        # both full of small launches and host round trips (r x r eigh, convergence tests) that
+        # would otherwise leave the device idle in front of it.
+        side = self._side_stream()
+        if side is not None:
+            main = torch.cuda.current_stream(self._W.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                grad = self._block_gradient(loc, self.system.B[:, cols], blk_d)
+            blk_precond = self._get_precond(blk)
+            eta = self._get_stepsize(blk, blk_precond)
+            main.wait_stream(side)
+            grad.record_stream(main)
+        else:
+            blk_precond = self._get_precond(blk)
+            eta = self._get_stepsize(blk, blk_precond)
+            grad = self._block_gradient(loc, self.system.B[:, cols], blk_d)
+        d = blk_precond._inv @ grad
         if not self.accel:
             Wm = self._W[:, cols]
             Wm[blk_d] -= eta * d

@@ -46,12 +46,14 @@ def time_call(fn, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("variants", nargs="+")
-    ap.add_argument("--kernel", default="symm", choices=["symm", "skinny"])
+    ap.add_argument("--kernel", default="symm", choices=["symm", "skinny", "kmatmat"])
     ap.add_argument("--n", type=int, default=200000)
     ap.add_argument("--rows", type=int, default=50000)
     ap.add_argument("--k", type=int, default=1)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--store", default="same", choices=["same", "f32"], help="symm: packed storage dtype")
+    ap.add_argument("--d", type=int, default=50, help="kmatmat: features")
+    ap.add_argument("--blk", type=int, default=5000, help="kmatmat: gathered rows (row oracle)")
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--reps", type=int, default=7)
     a = ap.parse_args()
@@ -77,6 +79,22 @@ def main():
             def fn():
                 rc = lib.rk_symm_matmat(dti, sti, Kp.data_ptr(), n, 0, 1, V.data_ptr(), k, k, 1.0, 0.1,
                                         Y.data_ptr(), k, ws.data_ptr(), wsn, stream)
+                assert rc == 0, lib.rk_last_error()
+            return fn
+    elif a.kernel == "kmatmat":
+        X = torch.randn(n, a.d, dtype=dt, device=dev) / a.d**0.5
+        blk = torch.randperm(n, device=dev)[: a.blk].contiguous()
+        Y = torch.empty(a.blk, k, dtype=dt, device=dev)
+        nbytes = a.blk * n  # "bytes" column = pair evaluations here
+
+        def call(lib):
+            wsn = lib.rk_kernel_matmat_ws_bytes(dti, a.blk, n, k)
+            ws = torch.empty(max(wsn, 16), dtype=torch.uint8, device=dev)
+
+            def fn():
+                rc = lib.rk_kernel_matmat(dti, 0, X.data_ptr(), a.blk, a.d, blk.data_ptr(), X.data_ptr(), n,
+                                          a.d, None, a.d, 1.0, None, 1.0, V.data_ptr(), k, k, Y.data_ptr(),
+                                          k, 0, ws.data_ptr(), wsn, stream)
                 assert rc == 0, lib.rk_last_error()
             return fn
     else:
@@ -110,7 +128,8 @@ def main():
             res[v].append(time_call(fn, a.reps))
     for v, ts in res.items():
         med = statistics.median(ts)
-        print(f"{a.kernel} {v:12s} median {med:.3f} ms  ({nbytes / med / 1e6:.0f} GB/s)  rounds: "
+        unit = "Gpair/s" if a.kernel == "kmatmat" else "GB/s"
+        print(f"{a.kernel} {v:12s} median {med:.3f} ms  ({nbytes / med / 1e6:.0f} {unit})  rounds: "
               + " ".join(f"{t:.3f}" for t in ts), flush=True)
 
 
