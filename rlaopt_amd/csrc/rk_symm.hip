@@ -365,10 +365,10 @@ static size_t symm_ws_bytes(int64_t n, int64_t k, int64_t first, int64_t stride)
 
 // resident workgroups of the persistent strip kernel on this device (cached per instantiation)
 template <typename KernelT>
-static int64_t symm_resident_workgroups(KernelT kernel) {
+static int64_t symm_resident_workgroups(KernelT kernel, int wg_per_cu) {
     static int64_t cached = 0;
     if (cached == 0) {
-        int per_cu = RK_SYMM_WG_PER_CU, dev = 0, cus = 0;
+        int per_cu = wg_per_cu, dev = 0, cus = 0;
         if (per_cu <= 0 &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, SYMM_THREADS, 0) != hipSuccess)
             per_cu = 0;
@@ -400,7 +400,9 @@ static int symm_matmat_impl(const TS* Kp, int64_t n, int64_t first, int64_t stri
         for (int64_t t = 0; t < T_loc; ++t) total_items += ceil_div(L.rows(t), ITEM_ROWS);
 #define RK_SYMM(KK)                                                                             \
     {                                                                                           \
-        const int64_t resident = symm_resident_workgroups(symm_strip_kernel<TS, T, KK>);        \
+        /* measured (tools/ab.py): float64 storage, k = 1 prefers 5 workgroups per CU (+3 %) */   \
+        const int wg = (RK_SYMM_WG_PER_CU == 6 && sizeof(TS) == 8 && KK == 1) ? 5 : RK_SYMM_WG_PER_CU; \
+        const int64_t resident = symm_resident_workgroups(symm_strip_kernel<TS, T, KK>, wg);    \
         dim3 grid((unsigned)(total_items < resident ? total_items : resident));                 \
         hipLaunchKernelGGL((symm_strip_kernel<TS, T, KK>), grid, dim3(SYMM_THREADS), 0, st, Kp, L, V, \
                            ldv, Prow, Pcol, max_items, total_items);                            \

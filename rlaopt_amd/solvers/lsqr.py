@@ -22,6 +22,7 @@ import torch
 from ..ops import get_backend
 from ..preconditioners import IdentityConfig, PreconditionerConfig, SkPreConfig
 from ..preconditioners import _get_precond as _pf_get_precond
+from ..utils import quiet_host
 from .solver import Solver
 
 if TYPE_CHECKING:
@@ -93,6 +94,10 @@ class LSQR(Solver):
         return self.P._right_solve_t(g)
 
     def _step(self):
+        with quiet_host():  # (a no-op inside LinSys.solve, which already holds it)
+            self._step_impl()
+
+    def _step_impl(self):
         mask = self.system.mask
         if not bool(mask.any()):
             return
