@@ -45,7 +45,12 @@ def test_materialize_matches_reference_closed_form(be, prec, kind, ell, shape):
 
 @pytest.mark.parametrize("kind", ok.KINDS)
 @pytest.mark.parametrize(
-    "n1,n2,d,k", [(10, 5, 3, 1), (130, 257, 7, 3), (300, 1000, 40, 10), (65, 64, 33, 16), (70, 90, 5, 37)]
+    "n1,n2,d,k",
+    [(10, 5, 3, 1), (130, 257, 7, 3), (300, 1000, 40, 10), (65, 64, 33, 16), (70, 90, 5, 37),
+     # d > 40: the packed 64 x 128 float32 kernel (rows 4-, 8- and 16-byte aligned; one, two and
+     # three 64-feature chunks; ragged tiles; every KB instantiation; k > 16 in host chunks)
+     (70, 300, 41, 1), (129, 1000, 50, 10), (64, 128, 64, 16), (200, 515, 64, 2), (90, 260, 100, 4),
+     (65, 129, 130, 8), (33, 2100, 52, 37)],
 )
 def test_kernel_matmat_and_materialize_vs_oracle(be, prec, kind, n1, n2, d, k):
     dt = DTYPES[prec]
@@ -72,7 +77,12 @@ def test_kernel_index_oracles(be, prec):
     """row oracle K(X[blk], X) and block oracle K(X[blk], X[blk]) gathers (base.py:104-128)."""
     dt = DTYPES[prec]
     gen = torch.Generator().manual_seed(3)
-    n, d, k = 500, 9, 4
+    _index_oracle_case(be, dt, gen, 500, 9, 4)
+    _index_oracle_case(be, dt, gen, 700, 50, 10)  # packed wide kernel, 8-byte aligned rows
+    _index_oracle_case(be, dt, gen, 400, 64, 3)   # ... 16-byte aligned rows (coalesced staging)
+
+
+def _index_oracle_case(be, dt, gen, n, d, k):
     X = torch.randn(n, d, dtype=dt, generator=gen) / 3
     blk = torch.randperm(n, generator=gen)[:77]
     V = torch.randn(n, k, dtype=dt, generator=gen)
