@@ -109,7 +109,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n", type=int, default=200000)
+    ap.add_argument("--n", type=int, default=int(os.environ.get("RK_BENCH_N", "200000")),
+                    help="rows of the system (RK_BENCH_N sets it under torchrun, whose parser rejects --n)")
     ap.add_argument("--d", type=int, default=64)
     ap.add_argument("--rank", type=int, default=512)
     ap.add_argument("--callback-freq", type=int, default=10)

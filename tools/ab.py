@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--k", type=int, default=1)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--store", default="same", choices=["same", "f32"], help="symm: packed storage dtype")
+    ap.add_argument("--stride", type=int, default=1, help="symm: strips first, first+stride, ... (rank 0 of p)")
     ap.add_argument("--d", type=int, default=50, help="kmatmat: features")
     ap.add_argument("--blk", type=int, default=5000, help="kmatmat: gathered rows (row oracle)")
     ap.add_argument("--rounds", type=int, default=4)
@@ -67,17 +68,18 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     if a.kernel == "symm":
         X = torch.randn(n, 64, dtype=dt, device=dev) / 8
-        Kp = be.sympack_materialize("rbf", X, 1.0, store_dtype=torch.float32 if a.store == "f32" else None)
+        Kp = be.sympack_materialize("rbf", X, 1.0, store_dtype=torch.float32 if a.store == "f32" else None,
+                                    first=0, stride=a.stride)
         sti = _lib.RK_F32 if Kp.dtype == torch.float32 else _lib.RK_F64
         Y = torch.empty(n, k, dtype=dt, device=dev)
         nbytes = Kp.numel() * Kp.element_size()
 
         def call(lib):
-            wsn = lib.rk_symm_matmat_ws_bytes(dti, sti, n, k, 0, 1)
+            wsn = lib.rk_symm_matmat_ws_bytes(dti, sti, n, k, 0, a.stride)
             ws = torch.empty(wsn, dtype=torch.uint8, device=dev)
 
             def fn():
-                rc = lib.rk_symm_matmat(dti, sti, Kp.data_ptr(), n, 0, 1, V.data_ptr(), k, k, 1.0, 0.1,
+                rc = lib.rk_symm_matmat(dti, sti, Kp.data_ptr(), n, 0, a.stride, V.data_ptr(), k, k, 1.0, 0.1,
                                         Y.data_ptr(), k, ws.data_ptr(), wsn, stream)
                 assert rc == 0, lib.rk_last_error()
             return fn
