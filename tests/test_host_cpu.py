@@ -18,3 +18,28 @@ def dev():
 def oracle_backend():
     with use_backend(OracleBackend()):
         yield
+
+
+def test_quiet_host_limits_and_restores_threads():
+    """utils.quiet_host: small CPU thread pool inside solver loops, re-entrant, restored on exit."""
+    from rlaopt_amd.utils import quiet_host, small_host_lapack
+
+    prev = torch.get_num_threads()
+    try:
+        torch.set_num_threads(max(prev, 4))
+        outer = torch.get_num_threads()
+        with quiet_host(max_threads=2):
+            assert torch.get_num_threads() == min(outer, 2)
+            with quiet_host(max_threads=1):  # nested: the outermost context decides
+                assert torch.get_num_threads() == min(outer, 2)
+                with small_host_lapack(64):
+                    assert torch.get_num_threads() == 1
+                assert torch.get_num_threads() == min(outer, 2)
+            assert torch.get_num_threads() == min(outer, 2)
+        assert torch.get_num_threads() == outer
+        with pytest.raises(RuntimeError):
+            with quiet_host(max_threads=2):
+                raise RuntimeError("boom")
+        assert torch.get_num_threads() == outer  # restored after an exception too
+    finally:
+        torch.set_num_threads(prev)
