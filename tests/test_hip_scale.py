@@ -3,9 +3,11 @@ BASELINE.json problem size (n = 200 000, d = 64) - without needing the reference
 
 * mid-size (n = 6000): a full LinSys/PCG solve on the GPU against the oracle's block PCG driven
   by the oracle's C kernel product on the host: same iteration count, same history.
-* full size: sampled rows of the fused / materialised products against the C oracle, symmetry
-  of the bilinear form, linearity, consistency of materialised and matrix-free modes, and the
-  row-shard decomposition (concat of shard products == whole product).
+* full size: sampled rows of the fused / materialised / strip-packed products against the C
+  oracle, symmetry of the bilinear form, linearity, consistency of the three storage modes, the
+  row-shard decomposition (concat of shard products == whole product) and the cyclic strip
+  distribution (sum of the 8 ranks' partials == whole product), bitwise reproducibility;
+  the 2M x 512 LSQR round trip (BASELINE config 4) and the ASkotch-size row oracle (config 5).
 """
 
 import pytest
@@ -189,3 +191,86 @@ def test_float32_storage_float64_iteration(be, monkeypatch):
     # a wide product (sketch path) goes through float32 panels and comes back as float64
     wide = A @ torch.randn(n, 40, dtype=torch.float64, generator=g).to(DEV)
     assert wide.dtype == torch.float64 and wide.shape == (n, 40)
+
+
+def test_fullsize_packed_symmetric_product(be, full_problem):
+    """The dominant kernel at the BASELINE size: strip-packed n = 200 000 triangle (80 GB, fp32).
+    Against the matrix-free product (independent kernel), sampled rows of the C oracle, the
+    cyclic p = 8 strip distribution (partials of the 8 ranks add up to the whole product) and
+    run-to-run bitwise reproducibility."""
+    X, u, v = full_problem
+    n = X.shape[0]
+    Xd, vd = X.to(DEV), v.to(DEV)
+    reg = 1e-6 * n
+    Kp = be.sympack_materialize("rbf", Xd, 1.0)
+    assert Kp.numel() * 4 > 80e9
+    y = be.symm_matmat(Kp, n, vd, diag_shift=reg)
+    y2 = be.symm_matmat(Kp, n, vd, diag_shift=reg)
+    assert torch.equal(y, y2)  # fixed-order partial sums: bitwise reproducible
+    free = be.kernel_matmat("rbf", Xd, Xd, 1.0, vd) + reg * vd
+    assert float((y - free).norm() / free.norm()) < 1e-5
+    rows = torch.tensor([0, 255, 256, 1023, 1024, 77777, 100000, 199679, 199680, 199999])
+    want = cbind.kernel_matmat("rbf", X[rows], X, 1.0, v) + reg * v[rows]
+    got = y[rows.to(DEV)].cpu()
+    assert float((got - want).norm() / want.norm()) < 2e-5
+    # one right-hand side, and symmetry of the bilinear form through the packed operator
+    y1 = be.symm_matmat(Kp, n, vd[:, 0].contiguous(), diag_shift=reg)
+    assert float((y1 - y[:, 0]).norm() / y[:, 0].norm()) < 1e-5
+    ud = u.to(DEV)
+    Ku = be.symm_matmat(Kp, n, ud)
+    Kv = y - reg * vd
+    a = (ud.double() * Kv.double()).sum(0)
+    b = (vd.double() * Ku.double()).sum(0)
+    assert float(((a - b).abs() / a.abs().clamp_min(1.0)).max()) < 1e-4
+    del Kp, Ku, free
+    torch.cuda.empty_cache()
+    # the 8-rank layout: rank r owns strips r, r + 8, ...; the partial products add up
+    total = torch.zeros_like(y)
+    for r in range(8):
+        Kr = be.sympack_materialize("rbf", Xd, 1.0, first=r, stride=8)
+        total += be.symm_matmat(Kr, n, vd, first=r, stride=8)
+        del Kr
+    assert float((total - Kv).norm() / Kv.norm()) < 1e-5
+
+
+def test_fullsize_lsqr_recovers_planted_solution():
+    """BASELINE config 4 shape: 2 000 000 x 512 float64 (8 GB), column scales over 4 decades,
+    consistent right-hand side b = A x*: SkPre-preconditioned LSQR recovers x* (a size-
+    independent round trip; the LSQR restatement itself is pinned against scipy at small sizes)."""
+    from rlaopt_amd.models import LeastSquares
+    from rlaopt_amd.preconditioners import SkPreConfig
+    from rlaopt_amd.solvers import LSQRConfig
+
+    m, d = 2_000_000, 512
+    A = torch.empty(m, d, dtype=torch.float64, device=DEV)
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    A.normal_(generator=gen)
+    A *= torch.logspace(0, -4, d, dtype=torch.float64, device=DEV)
+    x_true = torch.randn(d, 1, dtype=torch.float64, device=DEV, generator=gen)
+    b = A @ x_true
+    system = LeastSquares(A, b, reg=0.0)
+    cfg = LSQRConfig(device=DEV, max_iters=200, atol=0.0, rtol=1e-12,
+                     precond_config=SkPreConfig(sketch_size=2048, rho=1e-12, sketch="sparse"))
+    W, log = system.solve(cfg, torch.zeros(d, 1, dtype=torch.float64, device=DEV), callback_freq=5)
+    assert max(log) <= 100
+    assert float((W - x_true).norm() / x_true.norm()) < 1e-8
+    res = float((A @ W - b).norm() / b.norm())
+    assert res < 1e-11
+
+
+def test_askotch_size_row_oracle_against_c_oracle(be):
+    """BASELINE config 5 shape: the blk x n row-oracle product (5 000 x 500 000, d = 50, k = 10,
+    fp32: the packed 64 x 128 fused kernel with in-kernel index gather) against the C oracle on
+    sampled rows of the block, and against gathering the rows on the host side first."""
+    n, d, k, blk_sz = 500_000, 50, 10, 5000
+    g = torch.Generator().manual_seed(0)
+    X = (torch.randn(n, d, dtype=torch.float64, generator=g) / d**0.5).float()
+    V = torch.randn(n, k, dtype=torch.float64, generator=g).float()
+    blk = torch.randperm(n, generator=g)[:blk_sz]
+    Xd, Vd, bd = X.to(DEV), V.to(DEV), blk.to(DEV)
+    got = be.kernel_matmat("rbf", Xd, Xd, 1.0, Vd, idx1=bd)
+    pick = torch.tensor([0, 1, 63, 64, 2500, 4998, 4999])
+    want = cbind.kernel_matmat("rbf", X[blk[pick]], X, 1.0, V)
+    assert float((got[pick.to(DEV)].cpu() - want).norm() / want.norm()) < 2e-5
+    pre = be.kernel_matmat("rbf", Xd[bd], Xd, 1.0, Vd)
+    assert float((got - pre).norm() / pre.norm()) < 1e-6
