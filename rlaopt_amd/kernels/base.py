@@ -502,6 +502,25 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
             return None  # generic path (A @ X, then + shift * X)
         return self.local_matmat(X, diag_shift=shift).to(X.device)
 
+    def _rk_spmd_matmat_gram(self, X_full: torch.Tensor, shift: float):
+        """SPMD + strip-packed storage: ((K + shift I) X)[rows_i] and X^T (K + shift I) X from ONE
+        all-reduce.  Every rank holds a full-length partial of K X, so its share of the Gram
+        block is X^T partial_i; it rides behind the partial in the same (float64) buffer.  The
+        shift term is added by rank 0 only, so the sum contains it exactly once.  Returns None
+        when this layout does not apply (the caller then uses product + separate Gram)."""
+        if self._sym is None or not self._spmd or X_full.ndim != 2 or X_full.shape[1] > _SYM_MAX_COLS:
+            return None
+        be = get_backend()
+        n, k = X_full.shape
+        lo, hi = self.row_range
+        X_full = X_full.to(self._sym.X.device)
+        part = self._sym.partial_matmat(X_full, diag_shift=shift if self._rank == 0 else 0.0)
+        gram = be.rmatmat(X_full, part, out_f64=True)
+        both = torch.cat([part.reshape(-1).double(), gram.reshape(-1)])
+        _dist.all_reduce_sum(both, self._group)
+        Y = both[: n * k].view(n, k)[lo:hi].to(X_full.dtype)
+        return Y, both[n * k :].view(k, k).clone()
+
     @property
     def row_range_all(self):
         return self._A1_bounds

@@ -69,6 +69,27 @@ class _ExecContext:
             _dist.all_reduce_sum(G, self.group)
         return G
 
+    def shifted_matmat_with_gram(self, X_loc: torch.Tensor):
+        """((A + reg I) X)[local rows] and X^T (A + reg I) X.  Row-sharded operators that can
+        fold the Gram block into the product's own collective do so (one all-reduce instead of
+        two per PCG iteration); everything else computes the two separately."""
+        fused = getattr(self.A, "_rk_spmd_matmat_gram", None) if self.sharded else None
+        if fused is not None:
+            out = fused(self.gather_rows(X_loc), self.reg)
+            if out is not None:
+                return out
+        AX = self.shifted_matmat(X_loc)
+        return AX, self.gram(X_loc, AX)
+
+    def precond_apply_with_gram(self, P, R_loc: torch.Tensor):
+        """Z = P^-1 R and R^T Z; one collective when the (row-sharded) preconditioner can fuse
+        them (Nystrom), otherwise apply + separate Gram."""
+        fused = getattr(P, "_inverse_matmul_with_gram", None) if self.sharded else None
+        if fused is not None and R_loc.ndim == 2:
+            return fused(R_loc)
+        Z = P._inv @ R_loc
+        return Z, self.gram(R_loc, Z)
+
     def col_norms(self, X: torch.Tensor) -> torch.Tensor:
         return self.gram(X, X).diagonal().clamp_min(0.0).sqrt()
 

@@ -154,6 +154,26 @@ class Nystrom(Preconditioner):
         out = be.matmat(self.U, t.to(X.dtype), alpha=-inv_rho, beta=inv_rho, C=X)
         return out[:, 0] if unsqueeze else out
 
+    def _inverse_matmul_with_gram(self, X: torch.Tensor):
+        """(Z, X^T Z) with Z = P^-1 X for a row-sharded n_loc x k block, in ONE collective: with
+        c = U^T X,  P^-1 X = (X - U M c) / rho  and  X^T P^-1 X = (X^T X - c^T M c) / rho,  so the
+        partial c and X^T X of every rank travel in the same all-reduce (block PCG needs both,
+        pcg.py:79-81; separately they cost two latency-bound collectives per iteration)."""
+        be = get_backend()
+        M = self._apply_factor()
+        r, k = self.U.shape[1], X.shape[1]
+        c = be.rmatmat(self.U, X, out_f64=True)   # r x k, float64
+        xx = be.rmatmat(X, X, out_f64=True)       # k x k, float64
+        both = torch.cat([c.reshape(-1), xx.reshape(-1)])
+        if self._sharded:
+            _dist.all_reduce_sum(both, self._group)
+        c, xx = both[: r * k].view(r, k), both[r * k :].view(k, k)
+        t = be.matmat(M, c) if M.ndim == 2 else c * M[:, None]
+        inv_rho = 1.0 / float(self.config.rho)
+        Z = be.matmat(self.U, t.to(X.dtype), alpha=-inv_rho, beta=inv_rho, C=X)
+        XtZ = (xx - c.T @ t) * inv_rho
+        return Z, 0.5 * (XtZ + XtZ.T)
+
     def _inverse_matmul_1d(self, x):
         return self._inverse_matmul_general(x, unsqueeze=True)
 

@@ -15,8 +15,10 @@ the logging iterations, like the reference's termination test).
 
 Converged columns (system.mask False) are dropped by compacting the n x k state to the
 active columns when the mask changes (the reference re-slices every array on every step,
-pcg.py:54-90).  With a row-sharded operator the state is row-partitioned across ranks: the
-search directions are all-gathered before the product and every Gram block is all-reduced.
+pcg.py:54-90).  With a row-sharded operator the state is row-partitioned across ranks.  Per
+iteration: one all-gather of the search directions, one all-reduce carrying the partial product
+together with P^T AP, and one carrying U^T R together with R^T R (from which R^T Z follows) - the
+Gram blocks ride in the collectives the product and the preconditioner need anyway.
 """
 
 from __future__ import annotations
@@ -57,9 +59,8 @@ class PCG(Solver):
         self.P = self._get_precond()
         self._Wc = self._W_all.clone()
         self._Rc = ctx.residual(self._Wc)  # B - (A W + reg W), local rows
-        Z = self.P._inv @ self._Rc
+        Z, self.RZ = ctx.precond_apply_with_gram(self.P, self._Rc)  # RZ: k x k float64 on the device
         self._Pc = Z.clone()
-        self.RZ = ctx.gram(self._Rc, Z)  # k x k float64 on the device
         self._AP_next = None  # (A + reg I) P computed ahead of time by _fused_log_product
 
     # reference attribute names, as full arrays (debug / tests)
@@ -128,12 +129,12 @@ class PCG(Solver):
         be, ctx = self._be, self._ctx
         AP, self._AP_next = self._AP_next, None
         if AP is None:
-            AP = ctx.shifted_matmat(self._Pc)        # (A + reg I) P, local rows
-        PAP = ctx.gram(self._Pc, AP)
+            AP, PAP = ctx.shifted_matmat_with_gram(self._Pc)  # (A + reg I) P, local rows; P^T AP
+        else:
+            PAP = ctx.gram(self._Pc, AP)
         alpha = be.small_solve(PAP, self.RZ)
         be.pcg_update_wr(self._Wc, self._Rc, self._Pc, AP, alpha)
-        Z = self.P._inv @ self._Rc
-        RZ_new = ctx.gram(self._Rc, Z)
+        Z, RZ_new = ctx.precond_apply_with_gram(self.P, self._Rc)
         beta = be.small_solve(self.RZ, RZ_new)
         be.pcg_update_p(self._Pc, Z, beta)
         self.RZ = RZ_new

@@ -123,6 +123,32 @@ def main():
         got = torch.stack([log[i]["metrics"]["internal_metrics"]["rel_res"] for i in early])
         want = torch.stack([logref[i]["rel_res"] for i in early])
         torch.testing.assert_close(got, want, rtol=1e-6, atol=0)
+        # collectives per block-PCG iteration with strip-packed SPMD storage: one all-gather
+        # (search directions), one all-reduce (partial product + P^T AP), one all-reduce
+        # (U^T R + R^T R); the Gram blocks do not get collectives of their own
+        if A.storage_mode.startswith("sympack"):
+            from rlaopt_amd.solvers.pcg import PCG
+
+            with sketches.inject(Om):  # (a fresh system: the solved one has every column masked out)
+                sv = PCG(LinSys(A, B, reg=reg), torch.zeros_like(B), cfg.precond_config, cpu)
+            calls = {"all_reduce": 0, "all_gather": 0}
+            ar, ag = rdist.all_reduce_sum, rdist.all_gather_rows
+
+            def count_ar(t, group=None):
+                calls["all_reduce"] += 1
+                return ar(t, group)
+
+            def count_ag(local, sizes, group=None):
+                calls["all_gather"] += 1
+                return ag(local, sizes, group)
+
+            rdist.all_reduce_sum, rdist.all_gather_rows = count_ar, count_ag
+            try:
+                for _ in range(3):
+                    sv._step()
+            finally:
+                rdist.all_reduce_sum, rdist.all_gather_rows = ar, ag
+            assert calls == {"all_reduce": 6, "all_gather": 3}, calls
         # every rank returns the same full solution
         Wsum = W.clone()
         td.all_reduce(Wsum)

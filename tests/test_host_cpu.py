@@ -43,3 +43,32 @@ def test_quiet_host_limits_and_restores_threads():
         assert torch.get_num_threads() == outer  # restored after an exception too
     finally:
         torch.set_num_threads(prev)
+
+
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+def test_nystrom_inverse_with_gram_matches_apply_then_gram(dt):
+    """Nystrom._inverse_matmul_with_gram (the one-collective form used by row-sharded PCG):
+    Z equals P^-1 X and the k x k block equals X^T Z computed from Z."""
+    from rlaopt_amd import sketches
+    from rlaopt_amd.preconditioners import NystromConfig
+    from rlaopt_amd.preconditioners import _get_precond
+
+    g = torch.Generator().manual_seed(11)
+    n, r, k = 300, 40, 3
+    Q, _ = torch.linalg.qr(torch.randn(n, n, dtype=torch.float64, generator=g))
+    A = ((Q * torch.arange(1, n + 1, dtype=torch.float64) ** -2.0) @ Q.T).to(dt)
+    A = 0.5 * (A + A.T)
+    X = torch.randn(n, k, dtype=dt, generator=g)
+    Om = (torch.randn(r, n, dtype=dt, generator=g) / r**0.5).T.contiguous()
+    with use_backend(OracleBackend()):
+        P = _get_precond(NystromConfig(rank=r, rho=1e-3, sketch="gauss"))
+        with sketches.inject(Om):
+            P._update(A, torch.device("cpu"))
+        P._update_damping(baseline_rho=1e-3)
+        Z, XtZ = P._inverse_matmul_with_gram(X)
+        Zref = P._inv @ X
+    tol = 1e-10 if dt == torch.float64 else 2e-4
+    torch.testing.assert_close(Z, Zref, rtol=tol, atol=tol)
+    want = X.double().T @ Zref.double()
+    assert XtZ.dtype == torch.float64
+    assert float((XtZ - want).abs().max() / want.abs().max()) < (1e-9 if dt == torch.float64 else 1e-4)
