@@ -80,6 +80,7 @@ def _same_points(A1: torch.Tensor, A2: torch.Tensor) -> bool:
 
 
 _PANEL_BYTES = 16 << 30  # temporary row-major panel for wide products in sympack mode (>= 512 GEMM tiles)
+_BLK_MATERIALIZE_BYTES = 1 << 30  # block oracles up to this size are materialised (SAP blocks)
 _SYM_MAX_COLS = 16      # beyond this many columns a product goes through panels + MFMA
 
 
@@ -564,9 +565,18 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
             cfg = self._kernel_config_devices[dev]
             A1c = self._A1[blk[lo:hi].to(self._A1.device)].to(dev)
             A2b = self._A2[blk.to(self._A2.device)].to(dev)
+            if 0 < (hi - lo) * blk.shape[0] * A1c.element_size() <= _BLK_MATERIALIZE_BYTES:
+                # a block this small is written out once (|blk|^2 pair evaluations) and every
+                # later product streams it: one SAP step multiplies with K_bb ~17 times (7 sketch
+                # passes of 16 columns, <= 10 power iterations) - measured 2 ms of a 17 ms step
+                Kb = be.kernel_materialize(self._kind, A1c, A2b, cfg.lengthscale, scale=self._scaling)
 
-            def matvec(x, A1c=A1c, A2b=A2b, cfg=cfg):
-                return be.kernel_matmat(self._kind, A1c, A2b, cfg.lengthscale, x, scale=self._scaling)
+                def matvec(x, Kb=Kb):
+                    return be.matmat(Kb, x)
+            else:
+
+                def matvec(x, A1c=A1c, A2b=A2b, cfg=cfg):
+                    return be.kernel_matmat(self._kind, A1c, A2b, cfg.lengthscale, x, scale=self._scaling)
 
             ops.append(LinOp(device=dev, shape=shape, matvec=matvec, matmat=matvec, dtype=self.dtype))
         return _DistributedLinOp(
