@@ -186,82 +186,108 @@ kmat_matmat_finish(const T* __restrict__ part, int S, int64_t n1, int k, T scale
 // the 16 lanes of a row read 16 consecutive float4 (the point-major layout of the 4 x 4 kernel
 // is a 16-way bank conflict for KB = 16), and the y update is packed over row pairs.  The 16
 // lanes that share a row are one DPP row: their sums combine with 4 v_add_f32_dpp, no LDS.
+#ifndef RK_KMAT_PREFETCH
+// 1: load the next tile's panels while the current tile is computed.  Measured slower (10.1 vs
+// 8.9 ms on the ASkotch row oracle): the 38 extra live registers push the kernel over the 256
+// that two waves per SIMD allow.  What did pay is issuing all global loads of a panel before the
+// first LDS store (panel_load / panel_store): 10.0 -> 8.9 ms.
+#define RK_KMAT_PREFETCH 0
+#endif
 constexpr int TNW = 128;   // tile columns of the wide kernel
 constexpr int LDPW = 132;  // padded stride of its column panel
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Stage NP points x DCV features (chunk c0) into LDS feature-major, coalesced: a point's chunk
-// is contiguous in the row-major X, so lanes are laid along the features (VLD floats per lane,
-// 32 / VLD lanes per point) and a wave instruction touches 8 - 16 cache lines; the point-per-lane
-// gather of stage_panel touches 64 and was as expensive as the tile arithmetic.  VLD = 4 / 2 / 1
-// by the alignment of the rows (d = 50 rows are only 8-byte aligned).
-template <int NP, int DCV, int LD, int VLD>
-__device__ __forceinline__ void stage_panel_f32(float (*dst)[LD], int off,
-                                                const float* __restrict__ X, int64_t n, int64_t ldx,
-                                                const int64_t* __restrict__ idx, int64_t p0,
-                                                int64_t c0, int64_t d,
-                                                const float* __restrict__ ell_vec) {
-    constexpr int LPP = DCV / VLD;       // lanes per point
-    constexpr int PPP = 256 / LPP;       // points per pass of the workgroup
-    const int f = (threadIdx.x % LPP) * VLD;
-    const int pl = threadIdx.x / LPP;
+// Staging of NP points x DCV features (chunk c0) of a row-major X into a feature-major LDS panel,
+// split into a global -> register load and a register -> LDS store so that the loads of the NEXT
+// tile can be in flight while the current tile is being computed.  Two lane mappings:
+//  VLD = 4 / 2 : coalesced - a point's chunk is contiguous, so lanes are laid along the features
+//            (VLD floats per lane, DCV / VLD lanes per point); a wave instruction touches 8 - 16
+//            cache lines.  Needs 16- / 8-byte aligned rows.
+//  VLD = 0 : point per lane (any alignment): lane -> point, wave -> DCV/4 consecutive features.
+// Either way a thread holds NP * DCV / 256 values.
+template <int NP, int DCV, int VLD>
+__device__ __forceinline__ void panel_load_f32(float (&v)[NP * DCV / 256], const float* __restrict__ X,
+                                               int64_t n, int64_t ldx,
+                                               const int64_t* __restrict__ idx, int64_t p0,
+                                               int64_t c0, int64_t d,
+                                               const float* __restrict__ ell_vec) {
+    if constexpr (VLD == 0) {
+        const int pt = threadIdx.x & 63;
+        const int cg = threadIdx.x >> 6;  // 0..3
 #pragma unroll
-    for (int u = 0; u < NP / PPP; ++u) {
-        const int pt = pl + u * PPP;
-        const int64_t p = p0 + pt;
-        float v[VLD];
+        for (int half = 0; half < NP / 64; ++half) {
+            const int64_t p = p0 + half * 64 + pt;
+            const float* row = nullptr;
+            if (p < n) row = X + (idx ? idx[p] : p) * ldx;
 #pragma unroll
-        for (int e = 0; e < VLD; ++e) v[e] = 0.f;
-        if (p < n) {
-            const float* src = X + (idx ? idx[p] : p) * ldx + c0 + f;
-            if (c0 + f + VLD <= d) {
-                if constexpr (VLD == 4) {
-                    const float4 x = *reinterpret_cast<const float4*>(src);
-                    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-                } else if constexpr (VLD == 2) {
-                    const float2 x = *reinterpret_cast<const float2*>(src);
-                    v[0] = x.x; v[1] = x.y;
-                } else {
-                    v[0] = src[0];
+            for (int u = 0; u < DCV / 4; ++u) {
+                const int c = cg * (DCV / 4) + u;
+                float x = 0.f;
+                if (row != nullptr && c0 + c < d) {
+                    x = row[c0 + c];
+                    if (ell_vec) x = x / ell_vec[c0 + c];
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < VLD; ++e)
-                    if (c0 + f + e < d) v[e] = src[e];
-            }
-            if (ell_vec) {
-#pragma unroll
-                for (int e = 0; e < VLD; ++e)
-                    if (c0 + f + e < d) v[e] = v[e] / ell_vec[c0 + f + e];
+                v[half * (DCV / 4) + u] = x;
             }
         }
+    } else {
+        constexpr int LPP = DCV / VLD;   // lanes per point
+        constexpr int PPP = 256 / LPP;   // points per pass of the workgroup
+        const int f = (threadIdx.x % LPP) * VLD;
+        const int pl = threadIdx.x / LPP;
 #pragma unroll
-        for (int e = 0; e < VLD; ++e) dst[f + e][off + pt] = v[e];
+        for (int u = 0; u < NP / PPP; ++u) {
+            const int64_t p = p0 + pl + u * PPP;
+            float x[VLD];
+#pragma unroll
+            for (int e = 0; e < VLD; ++e) x[e] = 0.f;
+            if (p < n) {
+                const float* src = X + (idx ? idx[p] : p) * ldx + c0 + f;
+                if (c0 + f + VLD <= d) {
+                    if constexpr (VLD == 4) {
+                        const float4 q = *reinterpret_cast<const float4*>(src);
+                        x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+                    } else {
+                        const float2 q = *reinterpret_cast<const float2*>(src);
+                        x[0] = q.x; x[1] = q.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VLD; ++e)
+                        if (c0 + f + e < d) x[e] = src[e];
+                }
+                if (ell_vec) {
+#pragma unroll
+                    for (int e = 0; e < VLD; ++e)
+                        if (c0 + f + e < d) x[e] = x[e] / ell_vec[c0 + f + e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < VLD; ++e) v[u * VLD + e] = x[e];
+        }
     }
 }
 
-// point-per-lane staging (any alignment): lane -> point, wave -> DCV/4 consecutive features
-template <int DCV, int LD>
-__device__ __forceinline__ void stage_panel_pt_f32(float (*dst)[LD], int off,
-                                                   const float* __restrict__ X, int64_t n,
-                                                   int64_t ldx, const int64_t* __restrict__ idx,
-                                                   int64_t p0, int64_t c0, int64_t d,
-                                                   const float* __restrict__ ell_vec) {
-    const int pt = threadIdx.x & 63;
-    const int cg = threadIdx.x >> 6;  // 0..3
-    const int64_t p = p0 + pt;
-    const float* row = nullptr;
-    if (p < n) row = X + (idx ? idx[p] : p) * ldx;
+template <int NP, int DCV, int LD, int VLD>
+__device__ __forceinline__ void panel_store_f32(float (*dst)[LD], const float (&v)[NP * DCV / 256]) {
+    if constexpr (VLD == 0) {
+        const int pt = threadIdx.x & 63;
+        const int cg = threadIdx.x >> 6;
 #pragma unroll
-    for (int u = 0; u < DCV / 4; ++u) {
-        const int c = cg * (DCV / 4) + u;
-        float v = 0.f;
-        if (row != nullptr && c0 + c < d) {
-            v = row[c0 + c];
-            if (ell_vec) v = v / ell_vec[c0 + c];
-        }
-        dst[c][off + pt] = v;
+        for (int half = 0; half < NP / 64; ++half)
+#pragma unroll
+            for (int u = 0; u < DCV / 4; ++u)
+                dst[cg * (DCV / 4) + u][half * 64 + pt] = v[half * (DCV / 4) + u];
+    } else {
+        constexpr int LPP = DCV / VLD;
+        constexpr int PPP = 256 / LPP;
+        const int f = (threadIdx.x % LPP) * VLD;
+        const int pl = threadIdx.x / LPP;
+#pragma unroll
+        for (int u = 0; u < NP / PPP; ++u)
+#pragma unroll
+            for (int e = 0; e < VLD; ++e) dst[f + e][pl + u * PPP] = v[u * VLD + e];
     }
 }
 
@@ -298,19 +324,33 @@ kmat_matmat_wide_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
         for (int c = 0; c < KB; ++c) y2[h][c] = (f32x2)(0.f);
 
     const bool one_chunk = (d <= DCV);
-    auto stage_x = [&](int64_t c0) {
-        if constexpr (VLD == 0) stage_panel_pt_f32<DCV, LDP>(xs, 0, X1, n1, ldx1, idx1, i0, c0, d, ell_vec);
-        else stage_panel_f32<TM, DCV, LDP, VLD>(xs, 0, X1, n1, ldx1, idx1, i0, c0, d, ell_vec);
-    };
-    auto stage_y = [&](int64_t j0, int64_t c0) {
-        if constexpr (VLD == 0) {
-            stage_panel_pt_f32<DCV, LDPW>(ys, 0, X2, n2, ldx2, idx2, j0, c0, d, ell_vec);
-            stage_panel_pt_f32<DCV, LDPW>(ys, 64, X2, n2, ldx2, idx2, j0 + 64, c0, d, ell_vec);
-        } else {
-            stage_panel_f32<TNW, DCV, LDPW, VLD>(ys, 0, X2, n2, ldx2, idx2, j0, c0, d, ell_vec);
+    constexpr int VR = (TNW * KB + 255) / 256;  // V-slice values per thread
+    float xreg[TM * DCV / 256], yreg[TNW * DCV / 256], vreg[VR];
+    auto load_v = [&](int64_t j0) {  // V slice of a column tile, zero past k / n2
+#pragma unroll
+        for (int u = 0; u < VR; ++u) {
+            const int e = threadIdx.x + u * 256;
+            const int jj = e / KB, c = e - jj * KB;
+            const int64_t j = j0 + jj;
+            vreg[u] = (e < TNW * KB && j < n2 && c < k) ? V[j * ldv + c] : 0.f;
         }
     };
-    if (one_chunk) stage_x(0);
+    auto store_v = [&]() {  // rhs-major in LDS
+#pragma unroll
+        for (int u = 0; u < VR; ++u) {
+            const int e = threadIdx.x + u * 256;
+            if (e < TNW * KB) vs[e % KB][e / KB] = vreg[u];
+        }
+    };
+    const bool pipelined = one_chunk && RK_KMAT_PREFETCH;
+    if (one_chunk) {
+        panel_load_f32<TM, DCV, VLD>(xreg, X1, n1, ldx1, idx1, i0, 0, d, ell_vec);
+        panel_store_f32<TM, DCV, LDP, VLD>(xs, xreg);
+        if (pipelined && t_lo < t_hi) {  // first tile: nothing to overlap with yet
+            panel_load_f32<TNW, DCV, VLD>(yreg, X2, n2, ldx2, idx2, t_lo * TNW, 0, d, ell_vec);
+            load_v(t_lo * TNW);
+        }
+    }
     for (int64_t t = t_lo; t < t_hi; ++t) {
         const int64_t j0 = t * TNW;
         // acc[r][g][h]: row r, column group g (tx*4.. / 64 + tx*4..), columns (2h, 2h + 1) of it
@@ -323,17 +363,29 @@ kmat_matmat_wide_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
                 for (int h = 0; h < 2; ++h) acc[r][g][h] = (f32x2)(0.f);
         for (int64_t c0 = 0; c0 < d; c0 += DCV) {
             __syncthreads();  // readers of the previous panels / V slice are done
-            if (!one_chunk) stage_x(c0);
-            stage_y(j0, c0);
-            if (c0 == 0) {
-                // V slice of this column tile, rhs-major, zero padded to KB columns / past n2
-                for (int e = threadIdx.x; e < TNW * KB; e += 256) {
-                    const int jj = e / KB, c = e - jj * KB;
-                    const int64_t j = j0 + jj;
-                    vs[c][jj] = (j < n2 && c < k) ? V[j * ldv + c] : 0.f;
+            if (pipelined) {
+                // this tile's panel and V slice were loaded while the previous tile was computed;
+                // the next tile's loads are issued now and land during this tile's arithmetic
+                panel_store_f32<TNW, DCV, LDPW, VLD>(ys, yreg);
+                store_v();
+                __syncthreads();
+                if (t + 1 < t_hi) {
+                    panel_load_f32<TNW, DCV, VLD>(yreg, X2, n2, ldx2, idx2, j0 + TNW, 0, d, ell_vec);
+                    load_v(j0 + TNW);
                 }
+            } else {
+                if (!one_chunk) {
+                    panel_load_f32<TM, DCV, VLD>(xreg, X1, n1, ldx1, idx1, i0, c0, d, ell_vec);
+                    panel_store_f32<TM, DCV, LDP, VLD>(xs, xreg);
+                }
+                panel_load_f32<TNW, DCV, VLD>(yreg, X2, n2, ldx2, idx2, j0, c0, d, ell_vec);
+                panel_store_f32<TNW, DCV, LDPW, VLD>(ys, yreg);
+                if (c0 == 0) {
+                    load_v(j0);
+                    store_v();
+                }
+                __syncthreads();
             }
-            __syncthreads();
             const int nc = (int)((d - c0) < DCV ? (d - c0) : DCV);
             // operands of feature c + 1 are fetched from LDS while feature c is being used
             float4 xa = *reinterpret_cast<const float4*>(&xs[0][ty * 4]);
@@ -368,22 +420,21 @@ kmat_matmat_wide_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
                 for (int c = 0; c < nc; ++c) step(c);
             }
         }
-        // kernel values, packed over row pairs: kv[g][q][h] = (K[2h][col], K[2h+1][col])
-        f32x2 kv[2][4][2];
+        // kernel values packed over row pairs, kv[q][h] = (K[2h][col], K[2h+1][col]), one column
+        // group at a time (halves the registers the 16 + 16 values would hold at once)
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < 2; ++g) {
+            f32x2 kv[4][2];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const float a = kernel_value<float>(kind, acc[2 * h][g][q >> 1][q & 1], w);
                     const float b = kernel_value<float>(kind, acc[2 * h + 1][g][q >> 1][q & 1], w);
-                    kv[g][q][h] = (f32x2){a, b};
+                    kv[q][h] = (f32x2){a, b};
                 }
 #pragma unroll
-        for (int c = 0; c < KB; ++c) {
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int c = 0; c < KB; ++c) {
                 // zero entries past n2 kill padded pairs
                 const float4 v4 = *reinterpret_cast<const float4*>(&vs[c][g * 64 + tx * 4]);
                 const float vq[4] = {v4.x, v4.y, v4.z, v4.w};
@@ -392,7 +443,7 @@ kmat_matmat_wide_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
                     const f32x2 vv = (f32x2)(vq[q]);
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
-                        y2[h][c] = __builtin_elementwise_fma(kv[g][q][h], vv, y2[h][c]);
+                        y2[h][c] = __builtin_elementwise_fma(kv[q][h], vv, y2[h][c]);
                 }
             }
         }
@@ -482,6 +533,9 @@ static void launch_kmatmat(int KB, dim3 grid, hipStream_t st, int kind, const T*
 #ifndef RK_KMAT_WIDE
 #define RK_KMAT_WIDE 1
 #endif
+#ifndef RK_KMAT_KB12
+#define RK_KMAT_KB12 1
+#endif
 #ifndef RK_KMAT_COAL_MIN
 #define RK_KMAT_COAL_MIN 4  // coalesced staging only for 16-byte aligned rows (measured)
 #endif
@@ -532,6 +586,7 @@ static void launch_kmatmat_wide(int KB, dim3 grid, hipStream_t st, int kind, con
         case 2: RK_KMW(2); break;
         case 4: RK_KMW(4); break;
         case 8: RK_KMW(8); break;
+        case 12: RK_KMW(12); break;
         default: RK_KMW(16); break;
     }
 #undef RK_KMW
@@ -560,12 +615,13 @@ static int kmatmat_impl(int kind, const T* X1, int64_t n1, int64_t ldx1, const i
     dim3 grid((unsigned)ceil_div(n1, TM), (unsigned)p.S);
     if constexpr (sizeof(T) == 4) {
         if (kmat_tile_cols(true, d) == TNW) {
+            const int KBW = (RK_KMAT_KB12 && k > 8 && k <= 12) ? 12 : KB;  // ASkotch's k = 10
             if (kind == RK_LAPLACE)
-                launch_kmatmat_wide<true>(KB, grid, st, kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d,
+                launch_kmatmat_wide<true>(KBW, grid, st, kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d,
                                           w, ell_vec, (T)scale, V, (int)k, ldv, p.tiles_per_seg, part,
                                           Y, ldy, accumulate);
             else
-                launch_kmatmat_wide<false>(KB, grid, st, kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d,
+                launch_kmatmat_wide<false>(KBW, grid, st, kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d,
                                            w, ell_vec, (T)scale, V, (int)k, ldv, p.tiles_per_seg, part,
                                            Y, ldy, accumulate);
             int rcw = launch_status("rk_kernel_matmat");
