@@ -125,9 +125,12 @@ def real_step(overlap):
     mark("drain")
 
 
+from rlaopt_amd.utils import quiet_host
+
 for ov in (False, True):
-    for _ in range(R):
-        real_step(ov)
+    with quiet_host():  # what SAP._step holds (no spinning OpenMP workers next to the syncs)
+        for _ in range(R):
+            real_step(ov)
     print(f"--- host timeline, overlap={ov}")
     tot = 0.0
     for (o, name), v in stamps.items():
