@@ -83,6 +83,37 @@ with open(f"{dst}/{tag}_summary.md", "w") as f:
         f.write(f"`gemm_kernel<float,float,...>`: {sum(int(r['Calls']) for r in gem)} launches, {tot * 1e3:.1f} ms "
                 f"for 2 n^2 r + 4 n r^2 = {flops:.3e} flop -> **{flops / tot / 1e12:.1f} TFLOP/s** "
                 f"({100 * flops / tot / 157.3e12:.0f} % of the 157.3 TFLOP/s fp32 matrix peak, v_mfma_f32_32x32x2_f32).\n\n")
+    # matrix-core busy counter (own --pmc pass), if collected
+    mf = f"{src}/{tag}_pmc_mfma/{tag}_counter_collection.csv"
+    if os.path.exists(mf):
+        acc = {}
+        for r in csv.DictReader(open(mf)):
+            if "gemm_kernel<float, float" in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        if acc.get("SQ_VALU_MFMA_BUSY_CYCLES") and acc.get("GRBM_GUI_ACTIVE"):
+            busy = sum(acc["SQ_VALU_MFMA_BUSY_CYCLES"])
+            gui = sum(acc["GRBM_GUI_ACTIVE"])
+            sqb = sum(acc.get("SQ_BUSY_CYCLES", [0.0]))
+            f.write(f"PMC over the same GEMM launches: SQ_VALU_MFMA_BUSY_CYCLES = {busy:.4g}, "
+                    f"GRBM_GUI_ACTIVE = {gui:.4g}, SQ_BUSY_CYCLES = {sqb:.4g} (raw sums over launches; "
+                    f"MFMA busy / (GUI active x 1024 SIMDs) = {busy / (gui * 1024):.3f} if the busy "
+                    f"counter is summed over SIMDs, {busy / gui:.3f} if it is a per-device maximum).\n\n")
+    # the "next" rows: ASkotch and LSQR benches
+    for name, title in (("sap", "ASkotch / SAP (BASELINE config 5, tools/bench_sap.py)"),
+                        ("lsqr", "LSQR + SkPre (BASELINE config 4, tools/bench_lsqr.py)")):
+        blog = f"{src}/{tag}_bench_{name}.log"
+        st = f"{src}/{tag}_prof_{name}/{tag}_{name}_kernel_stats.csv"
+        if not (os.path.exists(blog) and os.path.exists(st)):
+            continue
+        shutil.copy(blog, f"{dst}/{tag}_bench_{name}.log")
+        shutil.copy(st, f"{dst}/{tag}_{name}_kernel_stats.csv")
+        line = [l for l in open(blog) if l.startswith("{")][-1].strip()
+        f.write(f"## {title}\n\nun-profiled run: `{line[:700]}`\n\n")
+        f.write("| kernel (rocprofv3 --stats of the same script) | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+        for r in list(csv.DictReader(open(st)))[:8]:
+            f.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | "
+                    f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
+        f.write("\n")
     f.write("## HBM traffic of the shard product (separate --pmc passes)\n\n")
     f.write(f"FETCH_SIZE = {fetch:.0f} KB, WRITE_SIZE = {write:.0f} KB per launch -> "
             f"(2 x FETCH + WRITE) x 1024 = {traffic / 1e9:.2f} GB vs algorithmic {algo / 1e9:.2f} GB "
