@@ -86,14 +86,15 @@ class HipBackend:
 
         class _T:
             def __enter__(self_inner):
-                if be._timing is None:
-                    return
+                self_inner.a = None
+                if be._timing is None or torch.cuda.is_current_stream_capturing():
+                    return  # (events recorded inside a graph capture cannot be timed)
                 self_inner.a = torch.cuda.Event(enable_timing=True)
                 self_inner.b = torch.cuda.Event(enable_timing=True)
                 self_inner.a.record(torch.cuda.current_stream(device))
 
             def __exit__(self_inner, *exc):
-                if be._timing is None:
+                if be._timing is None or self_inner.a is None:
                     return
                 self_inner.b.record(torch.cuda.current_stream(device))
                 be._timing.setdefault(op, []).append((self_inner.a, self_inner.b, nbytes))

@@ -23,6 +23,7 @@ Gram blocks ride in the collectives the product and the preconditioner need anyw
 
 from __future__ import annotations
 
+import os
 from typing import TYPE_CHECKING
 
 import torch
@@ -62,6 +63,10 @@ class PCG(Solver):
         Z, self.RZ = ctx.precond_apply_with_gram(self.P, self._Rc)  # RZ: k x k float64 on the device
         self._Pc = Z.clone()
         self._AP_next = None  # (A + reg I) P computed ahead of time by _fused_log_product
+        # opt-in: graph capture shares the process with whatever else holds device objects (a
+        # garbage collection that frees one mid-capture aborts the process)
+        self._use_graph = os.environ.get("RK_PCG_GRAPH", "0") == "1"
+        self._graph, self._graph_key, self._graph_AP, self._eager_tails = None, None, None, 0
 
     # reference attribute names, as full arrays (debug / tests)
     @property
@@ -132,9 +137,65 @@ class PCG(Solver):
             AP, PAP = ctx.shifted_matmat_with_gram(self._Pc)  # (A + reg I) P, local rows; P^T AP
         else:
             PAP = ctx.gram(self._Pc, AP)
+        if not self._tail_replay(AP, PAP):
+            self.RZ = self._tail(AP, PAP)
+
+    def _tail(self, AP, PAP):
+        """Everything after the operator product: alpha, W/R update, preconditioner apply, beta,
+        P update.  ~12 dependent launches on n x k vectors: launch-latency-bound once the product
+        is short (small systems, many GPUs).  Returns the new R^T Z."""
+        be, ctx = self._be, self._ctx
+        if PAP is None:
+            PAP = ctx.gram(self._Pc, AP)
         alpha = be.small_solve(PAP, self.RZ)
         be.pcg_update_wr(self._Wc, self._Rc, self._Pc, AP, alpha)
         Z, RZ_new = ctx.precond_apply_with_gram(self.P, self._Rc)
         beta = be.small_solve(self.RZ, RZ_new)
         be.pcg_update_p(self._Pc, Z, beta)
-        self.RZ = RZ_new
+        return RZ_new
+
+    # -- HIP graph of the tail -------------------------------------------------------------------
+    def _tail_graph_allowed(self) -> bool:
+        return (self._use_graph and self._Wc.is_cuda and not self._ctx.sharded
+                and type(self._be).__name__ == "HipBackend")
+
+    def _tail_replay(self, AP, PAP) -> bool:
+        """Replay the captured tail (capturing it first when the state buffers changed).  The
+        graph reads AP from a fixed buffer and leaves R^T Z in ``self.RZ`` in place, so nothing
+        it touches is re-bound between replays.  False -> caller runs the eager tail."""
+        if not self._tail_graph_allowed():
+            return False
+        self._eager_tails += 1
+        if self._eager_tails <= 2:  # first iterations eager: one-time allocations and module loads
+            return False
+        key = (self._Wc.data_ptr(), self._Rc.data_ptr(), self._Pc.data_ptr(), self.RZ.data_ptr(),
+               tuple(self._Wc.shape), id(self.P))
+        try:
+            if self._graph is None or self._graph_key != key:
+                import gc
+
+                self._graph_AP = torch.empty_like(AP)
+                self._graph_AP.copy_(AP)
+                g = torch.cuda.CUDAGraph()
+                gc_was_on = gc.isenabled()
+                gc.disable()  # no destructor of a device object may run while the stream captures
+                try:
+                    with torch.cuda.graph(g):
+                        rz = self._tail(self._graph_AP, None)
+                        self.RZ.copy_(rz)
+                finally:
+                    if gc_was_on:
+                        gc.enable()
+                self._graph, self._graph_key = g, key
+                # capture only records: the state is unchanged, fall through to the replay
+            else:
+                self._graph_AP.copy_(AP)
+            self._graph.replay()
+            return True
+        except Exception as e:  # capture not possible here: stay eager for good
+            import warnings
+
+            warnings.warn(f"rlaopt_amd: PCG tail graph disabled ({type(e).__name__}: {e})")
+            self._use_graph = False
+            self._graph = None
+            return False
