@@ -94,10 +94,14 @@ with open(f"{dst}/{tag}_summary.md", "w") as f:
             busy = sum(acc["SQ_VALU_MFMA_BUSY_CYCLES"])
             gui = sum(acc["GRBM_GUI_ACTIVE"])
             sqb = sum(acc.get("SQ_BUSY_CYCLES", [0.0]))
-            f.write(f"PMC over the same GEMM launches: SQ_VALU_MFMA_BUSY_CYCLES = {busy:.4g}, "
-                    f"GRBM_GUI_ACTIVE = {gui:.4g}, SQ_BUSY_CYCLES = {sqb:.4g} (raw sums over launches; "
-                    f"MFMA busy / (GUI active x 1024 SIMDs) = {busy / (gui * 1024):.3f} if the busy "
-                    f"counter is summed over SIMDs, {busy / gui:.3f} if it is a per-device maximum).\n\n")
+            # SQ_VALU_MFMA_BUSY_CYCLES is summed over the SIMDs (it equals #MFMA x 64 cycles: one
+            # v_mfma_f32_32x32x2_f32 = 4096 flop at 64 flop/clk/SIMD); GRBM_GUI_ACTIVE is reported
+            # once per XCD (8 of them) -> utilisation = busy / (gui / 8 x 1024 SIMDs)
+            util = busy / (gui / 8.0 * 1024.0)
+            f.write(f"PMC over the same GEMM launches (own pass): SQ_VALU_MFMA_BUSY_CYCLES = {busy:.4g} "
+                    f"(= {busy / 64:.4g} MFMA x 64 cycles; the flop count above / 4096 = {flops / 4096:.4g}), "
+                    f"GRBM_GUI_ACTIVE = {gui:.4g} summed over 8 XCDs, SQ_BUSY_CYCLES = {sqb:.4g} -> "
+                    f"**matrix-core utilisation {100 * util:.1f} %** of the 1024 SIMDs' MFMA issue slots.\n\n")
     # the "next" rows: ASkotch and LSQR benches
     for name, title in (("sap", "ASkotch / SAP (BASELINE config 5, tools/bench_sap.py)"),
                         ("lsqr", "LSQR + SkPre (BASELINE config 4, tools/bench_lsqr.py)")):
