@@ -57,14 +57,6 @@ __device__ __forceinline__ V16 load_stream(const void* p) {
     return __builtin_bit_cast(V16, raw);
 }
 
-// wave-wide sum (all 64 lanes end with the total)
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
 // wave total in lane 63 without LDS: 4 DPP adds inside each 16-lane row, then row broadcasts
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_fetch(float v) {
