@@ -82,7 +82,8 @@ def cpu_baseline(X, n, budget_s=12.0):
         "kind": "port",
         "sample": f"oracle/rk_oracle.c matrix-free RBF product, rows 0..{last[0]} of the n={n} d={X.shape[1]} "
                   f"system in {last[1]:.2f}s ({pair_rate / 1e9:.3f} Gpair/s on {cores} threads), "
-                  f"extrapolated to one full product x 1.1",
+                  f"extrapolated to one full product x 1.1; {spent:.1f}s of host work in all "
+                  f"(doubling row samples up to that one)",
         "gpair_per_s": pair_rate / 1e9,
     }
 
