@@ -188,6 +188,22 @@ int rk_gram_small(int dtype, const void* X, int64_t ldx, const void* Y, int64_t 
  * the iteration never reads a scalar back (no reference counterpart: SURVEY 8a row a14). */
 int rk_axpby_cols(int dtype, int64_t n, int64_t k, const void* X, int64_t ldx, const double* a,
                   void* Y, int64_t ldy, const double* b, void* stream);
+/* One pass over a tall A (m x n, row-major) for BOTH products of a Golub-Kahan / LSQR step:
+ *     U  <- A Z - U diag(coef)      (m x k, in place; coef: k float64 scalars on the device)
+ *     G   = A^T U_new               (n x k, float64)
+ *     ss  = column sums of U_new^2  (k, float64)
+ * A^T u for the normalised u = U_new / sqrt(ss) is G / sqrt(ss): the norm is not needed inside
+ * the pass, so A is read once per iteration instead of twice (rk_matmat_skinny followed by
+ * rk_matmat_skinny_t).  Supported when `rk_normal_pass_supported` says so: k = 1 (k = 2 for
+ * float64), n and lda multiples of the 16-byte vector width, n * sizeof <= 4 KiB; otherwise use
+ * the two products.
+ * No reference counterpart (the reference has no LSQR: SURVEY 8a row a14); the arithmetic
+ * follows Paige & Saunders 1982, section 4, steps 3(a)-(b). */
+int rk_normal_pass_supported(int dtype, int64_t m, int64_t n, int64_t lda, int64_t k);
+size_t rk_normal_pass_ws_bytes(int dtype, int64_t m, int64_t n, int64_t k);
+int rk_normal_pass(int dtype, const void* A, int64_t m, int64_t n, int64_t lda, const void* Z,
+                   int64_t k, int64_t ldz, void* U, int64_t ldu, const double* coef, double* G,
+                   double* ss, void* ws, size_t ws_bytes, void* stream);
 /* X = A^-1 B for k x k A and k x nrhs B (FLOAT64, device), LU with partial pivoting,
  * k <= 16, nrhs <= 16 (torch.linalg.solve at rlaopt/solvers/pcg.py:61,80). A and B are
  * not modified; X may alias B. */

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("RK_HIP_LIBRARY") or os.path.join(_HERE, "librk_hip.so
 
 RK_F32, RK_F64 = 0, 1
 KIND_IDS = {"rbf": 0, "laplace": 1, "matern12": 2, "matern32": 3, "matern52": 4}
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # name -> (restype, argtypes); must list every symbol declared in include/rk.h
 SIGNATURES = {
@@ -88,6 +88,13 @@ SIGNATURES = {
     ),
     "rk_axpby_cols": (
         c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
+    ),
+    "rk_normal_pass_supported": (c_int, [c_int, c_int64, c_int64, c_int64, c_int64]),
+    "rk_normal_pass_ws_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64]),
+    "rk_normal_pass": (
+        c_int,
+        [c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+         c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
     ),
     "rk_small_solve": (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rk_sparse_sign_apply": (

@@ -49,6 +49,14 @@ class LeastSquares(Model):
             return get_backend().rmatmat(self._A, U)
         return self._A.T @ U
 
+    def _normal_pass(self, Z, U, coef):
+        """U <- A Z - U diag(coef) and (A^T U_new, column sums of squares) from ONE pass over a
+        dense A, or None when A is an operator / the shape is unsupported."""
+        if not isinstance(self._A, torch.Tensor):
+            return None
+        fn = getattr(get_backend(), "normal_pass", None)
+        return fn(self._A, Z, U, coef) if fn is not None else None
+
     def _residual(self, W):
         if isinstance(self._A, torch.Tensor):
             return get_backend().matmat(self._A, W, alpha=-1.0, beta=1.0, C=self._B)

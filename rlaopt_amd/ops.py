@@ -403,6 +403,33 @@ class HipBackend:
         _lib.check(rc, "rk_axpby_cols")
         return Y
 
+    def normal_pass(self, A, Z, U, coef):
+        """One pass over the tall A for a Golub-Kahan step: U <- A Z - U diag(coef) in place;
+        returns (A^T U_new as float64 n x k, column sums of squares of U_new as float64 k), or
+        None when the shape is outside what the fused kernel supports (the caller then does the
+        two products).  ``coef``: float64 device vector of length k."""
+        dev = _req(A, Z, U, coef)
+        if A.ndim != 2 or Z.ndim != 2 or U.ndim != 2 or A.dtype != Z.dtype or A.dtype != U.dtype:
+            return None
+        m, n = A.shape
+        k = Z.shape[1]
+        Z, _ldz = _rowmajor(Z)  # (n x k: tiny; triangular solves hand back column-major results)
+        if (Z.shape[0] != n or U.shape != (m, k) or A.stride(1) != 1
+                or U.stride(1) != 1 or A.data_ptr() % 16 != 0 or coef.dtype != torch.float64
+                or not self._lib.rk_normal_pass_supported(_dt(A), m, n, A.stride(0), k)):
+            return None
+        G = torch.empty((n, k), dtype=torch.float64, device=dev)
+        ss = torch.empty(k, dtype=torch.float64, device=dev)
+        ws, wsn = self._workspace(dev, self._lib.rk_normal_pass_ws_bytes(_dt(A), m, n, k))
+        algo = (m * n + 2 * m * k + 2 * n * k) * A.element_size()
+        with self._timed("rk_normal_pass", dev, algo):
+            rc = self._lib.rk_normal_pass(
+                _dt(A), _ptr(A), m, n, A.stride(0), _ptr(Z), k, Z.stride(0), _ptr(U), U.stride(0),
+                _ptr(coef), _ptr(G), _ptr(ss), _ptr(ws), wsn, _stream(dev),
+            )
+        _lib.check(rc, "rk_normal_pass")
+        return G, ss
+
     def small_solve(self, A, B):
         """float64 device solve A X = B, A (k x k), B (k x nrhs), k, nrhs <= 16."""
         dev = _req(A, B)

@@ -7,14 +7,17 @@ is the triangular factor of the sketch-and-precondition Gram matrix (SkPre, rlao
 preconditioners/skpre.py:93-98) or the identity.  The reference has no LSQR (SURVEY.md 8a row
 a14); parity is pinned against ``oracle/lsqr.py`` / scipy instead.
 
-Device plan: the two m-long products per iteration (A z and A^T u; A is read twice, 2 m d s
-bytes - HBM-bound) are ``rk_matmat_skinny`` / ``rk_matmat_skinny_t``; the Golub-Kahan vector
+Device plan: for a dense A whose rows fit a wave's registers (n * sizeof <= 4 KiB, k <= 2) both
+m-long products of an iteration come out of ONE sweep over A (``rk_normal_pass``: beta is not
+needed inside the pass because A^T u = A^T(unnormalised u) / beta) - m d s bytes per iteration;
+otherwise they are ``rk_matmat_skinny`` / ``rk_matmat_skinny_t`` (A read twice, 2 m d s bytes); the Golub-Kahan vector
 updates are ``rk_axpby_cols`` with per-column coefficients held in device memory; all rotation
 scalars are k-vectors on the device, so an iteration never synchronises the host.
 """
 
 from __future__ import annotations
 
+import os
 from typing import TYPE_CHECKING
 
 import torch
@@ -63,6 +66,11 @@ class LSQR(Solver):
         self._phibar, self._rhobar = beta.clone(), self._alpha.clone()
         self._Y = torch.zeros_like(self._V)
         self._ones = torch.ones(B.shape[1], **f64)
+        # One-pass mode (dense A, shapes rk_normal_pass supports): the top block of u is kept
+        # UNNORMALISED together with 1/beta per column - u = _Ut * _uinv - because then
+        # beta u = A z - alpha u and A^T u both come out of a single sweep over A.
+        self._uinv = self._ones.clone()
+        self._one_pass = os.environ.get("RK_LSQR_ONE_PASS", "1") != "0"
 
     @property
     def W(self) -> torch.Tensor:
@@ -104,15 +112,31 @@ class LSQR(Solver):
         be = self._be
         # beta u = Ahat v - alpha u
         Z = self.P._right_solve(self._V)
-        T = self.system._matmat(Z)
         neg_alpha = -self._alpha
-        be.axpby_cols(T, None, self._Ut, neg_alpha)
-        if self._Ub is not None:
-            be.axpby_cols(Z, self._sq * self._ones, self._Ub, neg_alpha)
-        beta = self._norms(self._Ut, self._Ub)
-        self._scale(self._Ut, self._Ub, 1.0 / beta)
-        # alpha v = Ahat^T u - beta v
-        G = self._adjoint(self._Ut, self._Ub)
+        fused = self.system._normal_pass(Z, self._Ut, self._alpha * self._uinv) if self._one_pass else None
+        if fused is not None:
+            # one sweep over A: _Ut <- A z - alpha u (unnormalised), g = A^T _Ut, ss = |_Ut|^2
+            g_raw, ss = fused
+            if self._Ub is not None:
+                be.axpby_cols(Z, self._sq * self._ones, self._Ub, neg_alpha)
+                ss = ss + be.rmatmat(self._Ub, self._Ub, out_f64=True).diagonal()
+            beta = ss.clamp_min(0.0).sqrt()
+            self._uinv = 1.0 / beta
+            g = (g_raw * self._uinv).to(self._V.dtype)
+            if self._Ub is not None:
+                be.axpby_cols(self._Ub, self._uinv, self._Ub)
+                g = g + self._sq * self._Ub
+            G = self.P._right_solve_t(g)
+        else:
+            self._one_pass = False  # (decided at the first step; _Ut stays normalised from here on)
+            T = self.system._matmat(Z)
+            be.axpby_cols(T, None, self._Ut, neg_alpha)
+            if self._Ub is not None:
+                be.axpby_cols(Z, self._sq * self._ones, self._Ub, neg_alpha)
+            beta = self._norms(self._Ut, self._Ub)
+            self._scale(self._Ut, self._Ub, 1.0 / beta)
+            # alpha v = Ahat^T u - beta v
+            G = self._adjoint(self._Ut, self._Ub)
         be.axpby_cols(G, None, self._V, -beta)
         alpha = self._norms(self._V, None)
         be.axpby_cols(self._V, 1.0 / alpha, self._V)

@@ -7,6 +7,7 @@ __all__ = list(input_checkers.__all__) + list(logger.__all__)
 
 
 import contextlib as _contextlib
+import gc as _gc
 
 import torch as _torch
 
@@ -22,21 +23,29 @@ def quiet_host(max_threads: int = 8):
     a GPU host, every excursion into a parallel region leaves ~128 spinning workers behind, and
     a loop that synchronises with the device (SAP: eigh + power iteration per step) was measured
     to lose 45 ms out of every 100 ms to them (33 ms -> 18 ms per ASkotch step once limited).
-    Re-entrant; the previous thread count is restored when the outermost context exits."""
+    Re-entrant; the previous thread count is restored when the outermost context exits.
+
+    The same context parks the objects that already exist in the garbage collector's permanent
+    generation (``gc.freeze``): a full collection over the ~10^6 objects a process holds after
+    importing torch takes ~40 ms - 25 LSQR iterations - and otherwise strikes every few dozen
+    steps.  Collection stays enabled; it just no longer re-scans the frozen objects."""
     global _quiet_depth, _quiet_saved
     if _quiet_depth == 0:
         prev = _torch.get_num_threads()
         _quiet_saved = prev if prev > max_threads else None
         if _quiet_saved is not None:
             _torch.set_num_threads(max_threads)
+        _gc.freeze()
     _quiet_depth += 1
     try:
         yield
     finally:
         _quiet_depth -= 1
-        if _quiet_depth == 0 and _quiet_saved is not None:
-            _torch.set_num_threads(_quiet_saved)
-            _quiet_saved = None
+        if _quiet_depth == 0:
+            _gc.unfreeze()
+            if _quiet_saved is not None:
+                _torch.set_num_threads(_quiet_saved)
+                _quiet_saved = None
 
 
 @_contextlib.contextmanager

@@ -278,3 +278,47 @@ def test_gram_small_block_inner_products(be, prec, n, k1, k2):
     got = be.rmatmat(Z[:, 1:3], Z[:, 2:5], out_f64=True)
     want = Z[:, 1:3].double().T @ Z[:, 2:5].double()
     assert float((got - want).abs().max()) <= 1e-12 * max(1.0, float(want.abs().max())) * n**0.5
+
+
+@pytest.mark.parametrize("m,n,k,lda_pad", [(3, 8, 1, 0), (1000, 512, 1, 0), (4099, 128, 2, 0), (777, 100, 1, 4),
+                                           (5000, 256, 2, 8), (260, 2, 1, 0), (9000, 384, 1, 0)])
+def test_normal_pass_one_sweep(be, prec, m, n, k, lda_pad):
+    """rk_normal_pass: U <- A Z - U diag(coef), G = A^T U_new, ss = |U_new|^2 from one pass."""
+    dt = DTYPES[prec]
+    vw = 4 if dt == torch.float32 else 2
+    if n % vw or (n * (4 if dt == torch.float32 else 8)) > 4096 or (k == 2 and dt == torch.float32):
+        pytest.skip("shape outside the fused kernel (covered by test_normal_pass_unsupported_shapes)")
+    gen = torch.Generator().manual_seed(m + n + k)
+    Afull = torch.randn(m, n + lda_pad, dtype=dt, generator=gen)
+    A = Afull[:, :n]
+    Z = torch.randn(n, k, dtype=dt, generator=gen)
+    U = torch.randn(m, k, dtype=dt, generator=gen)
+    coef = torch.rand(k, dtype=torch.float64, generator=gen) + 0.5
+    Ad, Ud = Afull.to(dev())[:, :n], U.clone().to(dev())
+    out = be.normal_pass(Ad, Z.to(dev()), Ud, coef.to(dev()))
+    assert out is not None
+    G, ss = out
+    want_U = A.double() @ Z.double() - U.double() * coef
+    want_G = A.double().T @ want_U
+    assert G.dtype == torch.float64 and ss.dtype == torch.float64
+    assert rel_err(Ud.cpu(), want_U) < LIM[dt] * 5
+    assert rel_err(G.cpu(), want_G) < LIM[dt] * 20
+    assert rel_err(ss.cpu(), (want_U**2).sum(0)) < LIM[dt] * 20
+    # bitwise reproducible (fixed-order partial sums)
+    Ud2 = U.clone().to(dev())
+    G2, ss2 = be.normal_pass(Ad, Z.to(dev()), Ud2, coef.to(dev()))
+    assert torch.equal(G, G2) and torch.equal(ss, ss2) and torch.equal(Ud, Ud2)
+
+
+def test_normal_pass_unsupported_shapes(be):
+    """Shapes outside the fused kernel return None (the caller then does the two products)."""
+    A = torch.randn(100, 1026, dtype=torch.float64, device=dev())  # row longer than 4 KiB
+    Z = torch.randn(1026, 1, dtype=torch.float64, device=dev())
+    U = torch.randn(100, 1, dtype=torch.float64, device=dev())
+    c = torch.ones(1, dtype=torch.float64, device=dev())
+    assert be.normal_pass(A, Z, U, c) is None
+    A3 = torch.randn(100, 64, dtype=torch.float32, device=dev())  # k = 3
+    assert be.normal_pass(A3, torch.randn(64, 3, device=dev()), torch.randn(100, 3, device=dev()),
+                          torch.ones(3, dtype=torch.float64, device=dev())) is None
+    A5 = torch.randn(100, 66, dtype=torch.float32, device=dev())  # n not a multiple of 4
+    assert be.normal_pass(A5, torch.randn(66, 1, device=dev()), torch.randn(100, 1, device=dev()), c) is None

@@ -9,7 +9,7 @@ while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   out=build_var/$name; mkdir -p $out
   objs=""
-  for f in rk_skinny.hip rk_kernelmat.hip rk_gemm.hip rk_symm.hip rk_api.cpp; do
+  for f in rk_skinny.hip rk_kernelmat.hip rk_gemm.hip rk_symm.hip rk_normal.hip rk_api.cpp; do
     o=$out/${f%.*}.o
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-slp-vectorize $flags -x hip -c $SRC/$f -o $o &
     objs="$objs $o"
