@@ -194,9 +194,8 @@ int rk_axpby_cols(int dtype, int64_t n, int64_t k, const void* X, int64_t ldx, c
  *     ss  = column sums of U_new^2  (k, float64)
  * A^T u for the normalised u = U_new / sqrt(ss) is G / sqrt(ss): the norm is not needed inside
  * the pass, so A is read once per iteration instead of twice (rk_matmat_skinny followed by
- * rk_matmat_skinny_t).  Supported when `rk_normal_pass_supported` says so: k = 1 (k = 2 for
- * float64), n and lda multiples of the 16-byte vector width, n * sizeof <= 4 KiB; otherwise use
- * the two products.
+ * rk_matmat_skinny_t).  Supported when `rk_normal_pass_supported` says so: k <= 2, n and lda
+ * multiples of the 16-byte vector width, n * sizeof <= 4 KiB; otherwise use the two products.
  * No reference counterpart (the reference has no LSQR: SURVEY 8a row a14); the arithmetic
  * follows Paige & Saunders 1982, section 4, steps 3(a)-(b). */
 int rk_normal_pass_supported(int dtype, int64_t m, int64_t n, int64_t lda, int64_t k);

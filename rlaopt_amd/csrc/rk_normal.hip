@@ -86,6 +86,7 @@ normal_pass_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
         }
     };
     auto consume = [&](const V16 a[R][NS], T uo, int64_t i0) {
+        T ubuf = T(0);  // lane r*K + c collects U_new[i0 + r][c]: one coalesced store per group
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const bool live = i0 + r < i_hi;
@@ -107,11 +108,10 @@ normal_pass_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
                 const T tot = lane_value(wave_total_lane63(dot), 63);
                 unew[c] = tot - cf[c] * lane_value(uo, r * K + c);
             }
-            if (live) {
-                if (lane == 0) {
 #pragma unroll
-                    for (int c = 0; c < K; ++c) U[(i0 + r) * ldu + c] = unew[c];
-                }
+            for (int c = 0; c < K; ++c)
+                if (lane == r * K + c) ubuf = unew[c];
+            if (live) {
 #pragma unroll
                 for (int c = 0; c < K; ++c) {
                     ss[c] += (double)unew[c] * (double)unew[c];
@@ -122,6 +122,8 @@ normal_pass_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
                 }
             }
         }
+        // (a plain store: L2 merges the 16 - 64 byte pieces of neighbouring groups)
+        if (lane < R * K && i0 + lane / K < i_hi) U[(i0 + lane / K) * ldu + lane % K] = ubuf;
     };
     if (i_lo < i_hi) {
         int64_t i0 = i_lo;
@@ -165,8 +167,17 @@ normal_pass_finish(const double* __restrict__ part_g, const double* __restrict__
     const int64_t total = nk + k;  // the k sums of squares ride behind the n*k entries of G
     double sum = 0.0;
     if (e < total) {
-        for (int64_t w = ty; w < nwaves; w += NSL)
-            sum += e < nk ? part_g[w * nk + e] : part_ss[w * k + (e - nk)];
+        // four independent chains (the loads are latency-bound), combined in a fixed order
+        const double* src = e < nk ? part_g + e : part_ss + (e - nk);
+        const int64_t ld = e < nk ? nk : k;
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+        int64_t w = ty;
+        for (; w + 3 * NSL < nwaves; w += 4 * NSL) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s4[q] += src[(w + q * NSL) * ld];
+        }
+        for (int q = 0; w < nwaves; w += NSL, ++q) s4[q] += src[w * ld];
+        sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     }
     red[ty][tx] = sum;
     __syncthreads();
@@ -189,12 +200,11 @@ static NormalPlan plan_normal(int dtype, int64_t m, int64_t n, int64_t lda, int6
     NormalPlan p{0, 0, 0};
     const int vw = dtype == RK_F32 ? 4 : 2;
     if (m <= 0 || n <= 0 || k < 1 || k > 2 || n % vw != 0 || lda % vw != 0) return p;
-    if (k == 2 && dtype == RK_F32) return p;  // measured slower than the two products (5.0 vs 2.8 ms)
     const int64_t steps = ceil_div(n, (int64_t)64 * vw);
     p.ns = steps <= 1 ? 1 : (steps <= 2 ? 2 : (steps <= 4 ? 4 : 0));
     if (p.ns == 0) return p;
-    // ~8 waves per SIMD-slot round (8192 waves), at least 64 rows each
-    int64_t rpw = ceil_div(m, 8192);
+    // ~4096 waves (two rounds of the resident ones), at least 64 rows each
+    int64_t rpw = ceil_div(m, 4096);
     if (rpw < 64) rpw = 64;
     p.rows_per_wave = round_up(rpw, NP_ROW_ALIGN);
     p.nwaves = ceil_div(m, p.rows_per_wave);

@@ -312,10 +312,19 @@ symm_finish_kernel(SymLayout L, int K, const T* __restrict__ Prow, const T* __re
             items = (L.rows(tc) + ITEM_ROWS - 1) / ITEM_ROWS;
         }
         const int64_t jloc = i - blk * W;
-        for (int64_t u = ty; u < nrow + items; u += NS) {
-            if (u < nrow) sum += Prow[(L.row_offset(t0 + u) + i) * K + c];
-            else sum += Pcol[((tc * max_items + (u - nrow)) * W + jloc) * K + c];
+        // four independent chains (the loads are latency-bound), combined in a fixed order
+        auto term = [&](int64_t u) -> T {
+            return u < nrow ? Prow[(L.row_offset(t0 + u) + i) * K + c]
+                            : Pcol[((tc * max_items + (u - nrow)) * W + jloc) * K + c];
+        };
+        T s4[4] = {T(0), T(0), T(0), T(0)};
+        int64_t u = ty;
+        for (; u + 3 * NS < nrow + items; u += 4 * NS) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s4[q] += term(u + q * NS);
         }
+        for (int q = 0; u < nrow + items; u += NS, ++q) s4[q] += term(u);
+        sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     }
     red[ty][tx] = sum;
     __syncthreads();

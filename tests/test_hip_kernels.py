@@ -286,7 +286,7 @@ def test_normal_pass_one_sweep(be, prec, m, n, k, lda_pad):
     """rk_normal_pass: U <- A Z - U diag(coef), G = A^T U_new, ss = |U_new|^2 from one pass."""
     dt = DTYPES[prec]
     vw = 4 if dt == torch.float32 else 2
-    if n % vw or (n * (4 if dt == torch.float32 else 8)) > 4096 or (k == 2 and dt == torch.float32):
+    if n % vw or (n * (4 if dt == torch.float32 else 8)) > 4096:
         pytest.skip("shape outside the fused kernel (covered by test_normal_pass_unsupported_shapes)")
     gen = torch.Generator().manual_seed(m + n + k)
     Afull = torch.randn(m, n + lda_pad, dtype=dt, generator=gen)
