@@ -27,6 +27,7 @@ class LeastSquares(Model):
         self._reg = reg
         self._mask = torch.ones(self._B.shape[1], dtype=torch.bool)
         self._g0 = None
+        self._ones = None
 
     A = property(lambda self: self._A)
     B = property(lambda self: self._B)
@@ -66,16 +67,31 @@ class LeastSquares(Model):
         return get_backend().rmatmat(X, X, out_f64=True).diagonal().clamp_min(0.0).sqrt()
 
     def _compute_internal_metrics(self, W: torch.Tensor):
-        R = self._residual(W)
-        G = self._rmatmat(R)
-        if self._reg:
-            G = G - self._reg * W
+        """Normal-equations residual |A^T (b - A w) - reg w| (absolute, and relative to |A^T b|)
+        and the misfit |b - A w| per column.  For a dense A both products come out of one sweep
+        (rk_normal_pass with U = b, coef = 1: U <- A w - b = -r, G = -A^T r, ss = |r|^2)."""
         if self._g0 is None:
             self._g0 = self._col_norms(self._rmatmat(self._B))
+        k = self._B.shape[1]
+        fused = None
+        if isinstance(self._A, torch.Tensor) and W.ndim == 2:
+            if self._ones is None or self._ones.device != self._B.device:
+                self._ones = torch.ones(k, dtype=torch.float64, device=self._B.device)
+            fused = self._normal_pass(W, self._B.clone(), self._ones)
+        if fused is not None:
+            G, ss = fused
+            G = (-G).to(self._B.dtype)
+            misfit = ss.clamp_min(0.0).sqrt()
+        else:
+            R = self._residual(W)
+            G = self._rmatmat(R)
+            misfit = self._col_norms(R)
+        if self._reg:
+            G = G - self._reg * W
         abs_res = self._col_norms(G)
         dt = self._B.dtype
         return {"abs_res": abs_res.to(dt), "rel_res": (abs_res / self._g0).to(dt),
-                "misfit": self._col_norms(R).to(dt)}
+                "misfit": misfit.to(dt)}
 
     def _check_termination_criteria(self, internal_metrics: dict, atol: float, rtol: float):
         tol = torch.clamp(rtol * self._g0, min=atol)
