@@ -16,8 +16,9 @@
 // registers per lane.  R = 4 or 8 rows are in flight per stage, two stages (non-temporal loads issued
 // one group ahead).  Per row: K dot products (4 v_add_dpp + 2 row_bcast each, total read back with
 // v_readlane), u[i] stored by one lane, then NS * VW * K FMAs per lane into the G accumulators,
-// which stay in registers for the whole run and are written once, as float64, to a
-// (wave, column) table; a finishing kernel adds the tables in fixed order (bitwise reproducible).
+// which stay in registers for the whole run; the 4 waves of a workgroup add theirs through LDS and
+// write one float64 (workgroup, column) table; a finishing kernel adds the tables in fixed order
+// (bitwise reproducible).
 #include "rk_common.h"
 
 namespace rk {
@@ -38,8 +39,8 @@ normal_pass_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
     constexpr int R = np_rows(NS);
     const int lane = threadIdx.x & 63;
     const int64_t wid = uniform64((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
-    if (wid >= nwaves) return;
-    const int64_t i_lo = wid * rows_per_wave;
+    // (a wave past the last run of rows has an empty range; it still joins the barrier below)
+    const int64_t i_lo = wid * rows_per_wave < m ? wid * rows_per_wave : m;
     const int64_t i_hi = (i_lo + rows_per_wave < m) ? i_lo + rows_per_wave : m;
 
     // this lane's columns, its slice of Z, and its G accumulators
@@ -139,20 +140,28 @@ normal_pass_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
             i0 += R;
         }
     }
-    double* pg = part_g + wid * n * K;
+    // the workgroup's 4 waves add their tables in LDS (fixed order) and write one: the finishing
+    // kernel then reads a quarter of the partials
+    __shared__ double lg[4][64 * VW * NS * K];
+    __shared__ double lss[4][K];
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        if (!col_ok[s]) continue;
-        const int64_t j0 = ((int64_t)s * 64 + lane) * VW;
+    for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int e = 0; e < VW; ++e)
 #pragma unroll
-            for (int c = 0; c < K; ++c) pg[(j0 + e) * K + c] = (double)g[s][e][c];
-    }
+            for (int c = 0; c < K; ++c) lg[wv][((s * 64 + lane) * VW + e) * K + c] = (double)g[s][e][c];
     if (lane == 0) {
 #pragma unroll
-        for (int c = 0; c < K; ++c) part_ss[wid * K + c] = ss[c];
+        for (int c = 0; c < K; ++c) lss[wv][c] = ss[c];
     }
+    __syncthreads();
+    double* pg = part_g + (int64_t)blockIdx.x * n * K;
+    for (int64_t e = threadIdx.x; e < n * K; e += 256)
+        pg[e] = ((lg[0][e] + lg[1][e]) + lg[2][e]) + lg[3][e];
+    if (threadIdx.x < K)
+        part_ss[(int64_t)blockIdx.x * K + threadIdx.x] =
+            ((lss[0][threadIdx.x] + lss[1][threadIdx.x]) + lss[2][threadIdx.x]) + lss[3][threadIdx.x];
 }
 
 // G[e] = sum_w part_g[w][e] (e < n*k), ss[c] = sum_w part_ss[w][c]: 64 outputs x 16 slices per
@@ -215,9 +224,10 @@ template <typename T>
 static int normal_pass_impl(const NormalPlan& p, const T* A, int64_t m, int64_t n, int64_t lda,
                             const T* Z, int64_t k, int64_t ldz, T* U, int64_t ldu,
                             const double* coef, double* G, double* ss, void* ws, hipStream_t st) {
+    const int64_t ntab = ceil_div(p.nwaves, 4);  // one partial table per workgroup
     double* part_g = static_cast<double*>(ws);
-    double* part_ss = part_g + p.nwaves * n * k;
-    dim3 grid((unsigned)ceil_div(p.nwaves, 4));
+    double* part_ss = part_g + ntab * n * k;
+    dim3 grid((unsigned)ntab);
 #define RK_NP(KK, NSV)                                                                           \
     hipLaunchKernelGGL((normal_pass_kernel<T, KK, NSV>), grid, dim3(256), 0, st, A, m, n, lda, Z,  \
                        ldz, U, ldu, coef, part_g, part_ss, p.rows_per_wave, p.nwaves)
@@ -234,7 +244,7 @@ static int normal_pass_impl(const NormalPlan& p, const T* A, int64_t m, int64_t 
     int rc = launch_status("rk_normal_pass");
     if (rc != RK_OK) return rc;
     hipLaunchKernelGGL(normal_pass_finish, dim3((unsigned)ceil_div(n * k + k, 64)), dim3(1024), 0, st,
-                       part_g, part_ss, p.nwaves, n * k, (int)k, G, ss);
+                       part_g, part_ss, ntab, n * k, (int)k, G, ss);
     return launch_status("rk_normal_pass(finish)");
 }
 
@@ -248,7 +258,7 @@ extern "C" int rk_normal_pass_supported(int dtype, int64_t m, int64_t n, int64_t
 
 extern "C" size_t rk_normal_pass_ws_bytes(int dtype, int64_t m, int64_t n, int64_t k) {
     const NormalPlan p = plan_normal(dtype, m, n, n, k);
-    return p.ns ? (size_t)p.nwaves * (n * k + k) * sizeof(double) : 0;
+    return p.ns ? (size_t)ceil_div(p.nwaves, 4) * (n * k + k) * sizeof(double) : 0;
 }
 
 extern "C" int rk_normal_pass(int dtype, const void* A, int64_t m, int64_t n, int64_t lda,
@@ -265,7 +275,7 @@ extern "C" int rk_normal_pass(int dtype, const void* A, int64_t m, int64_t n, in
                "width with n*sizeof <= 4 KiB); use rk_matmat_skinny + rk_matmat_skinny_t",
                (long long)k, (long long)n);
     RK_REQUIRE(aligned16(A), "rk_normal_pass: A must be 16-byte aligned");
-    const size_t need = (size_t)p.nwaves * (n * k + k) * sizeof(double);
+    const size_t need = (size_t)ceil_div(p.nwaves, 4) * (n * k + k) * sizeof(double);
     if (ws == nullptr || ws_bytes < need) {
         set_error("rk_normal_pass: workspace %zu B < required %zu B", ws_bytes, need);
         return RK_ERR_WORKSPACE;
