@@ -11,7 +11,9 @@ while [ $# -ge 2 ]; do
   objs=""
   for f in rk_skinny.hip rk_kernelmat.hip rk_gemm.hip rk_symm.hip rk_normal.hip rk_api.cpp; do
     o=$out/${f%.*}.o
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-slp-vectorize $flags -x hip -c $SRC/$f -o $o &
+    slp=""  # same per-file flags as the Makefile
+    case $f in rk_skinny.hip|rk_symm.hip|rk_normal.hip) slp="-fno-slp-vectorize";; esac
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $slp $flags -x hip -c $SRC/$f -o $o &
     objs="$objs $o"
   done
   wait
