@@ -543,8 +543,13 @@ static void launch_kmatmat(int KB, dim3 grid, hipStream_t st, int kind, const T*
 #define RK_KMAT_WIDE_DCV64 1
 #endif
 // column-tile width of the fused product: the packed 64 x 128 kernel for float32
-static int kmat_tile_cols(bool is_f32, int64_t d) {
-    return (is_f32 && RK_KMAT_WIDE && d > 40) ? TNW : TN;  // short rows: the 4 x 4 kernel is faster
+// (measured with tools/ab.py --kernel kmatmat, 200 000 - 500 000 columns: the packed kernel wins
+// by 9 - 35 % for long rows (d >= 64 at k <= 2, d > 64 at any k) and for many right-hand sides
+// (k >= 5 from d = 44 on); the 4 x 4 kernel - 4 workgroups per CU instead of 2 - wins below that)
+static int kmat_tile_cols(bool is_f32, int64_t d, int64_t k) {
+    if (!is_f32 || !RK_KMAT_WIDE) return TN;
+    const bool wide = d > 64 || (d == 64 && k <= 2) || (d > 40 && k >= 5);
+    return wide ? TNW : TN;
 }
 
 template <bool L1>
@@ -601,7 +606,7 @@ static int kmatmat_impl(int kind, const T* X1, int64_t n1, int64_t ldx1, const i
                         int64_t ldv, T* Y, int64_t ldy, int accumulate, void* ws, size_t ws_bytes,
                         hipStream_t st) {
     const T w = ell_vec ? T(1) : T(1.0 / ell);
-    const KMPlan p = plan_kmatmat(n1, n2, kmat_tile_cols(sizeof(T) == 4, d));
+    const KMPlan p = plan_kmatmat(n1, n2, kmat_tile_cols(sizeof(T) == 4, d, k));
     T* part = nullptr;
     if (p.S > 1) {
         const size_t need = (size_t)p.S * n1 * k * sizeof(T);
@@ -614,7 +619,7 @@ static int kmatmat_impl(int kind, const T* X1, int64_t n1, int64_t ldx1, const i
     const int KB = k <= 1 ? 1 : (k <= 2 ? 2 : (k <= 4 ? 4 : (k <= 8 ? 8 : 16)));
     dim3 grid((unsigned)ceil_div(n1, TM), (unsigned)p.S);
     if constexpr (sizeof(T) == 4) {
-        if (kmat_tile_cols(true, d) == TNW) {
+        if (kmat_tile_cols(true, d, k) == TNW) {
             const int KBW = (RK_KMAT_KB12 && k > 8 && k <= 12) ? 12 : KB;  // ASkotch's k = 10
             if (kind == RK_LAPLACE)
                 launch_kmatmat_wide<true>(KBW, grid, st, kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d,
