@@ -132,7 +132,9 @@ sympack_materialize_kernel(int kind, const T* __restrict__ X, int64_t ldx, int64
 //    proportional to their volume (a quarter of the stores still costs 3 %), nor to which wave
 //    issues them (a dedicated writer wave changed nothing): reads and writes interleave badly
 //    at the HBM controller.  Larger per-workgroup tiles would shrink the tables, but 1 MiB
-//    items are already what the tail of a 1280-workgroup grid allows.
+//    items are already what the tail of a 1280-workgroup grid allows; a design with a fifth of
+//    the stores (4 strips per workgroup, column sums carried down a strip) was emulated by
+//    dropping the other stores: 2.1 % before its own costs - not pursued.
 //  * item order matters: ids interleaved over the persistent workgroups (the resident grid
 //    sweeps one contiguous window) beat a contiguous id range per workgroup by 1.2 % and a
 //    row-block-major order by 5 %.
