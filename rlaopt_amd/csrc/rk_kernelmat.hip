@@ -193,6 +193,9 @@ kmat_matmat_finish(const T* __restrict__ part, int S, int64_t n1, int k, T scale
 // first LDS store (panel_load / panel_store): 10.0 -> 8.9 ms.
 #define RK_KMAT_PREFETCH 0
 #endif
+#ifndef RK_KMAT_OCC3_KB
+#define RK_KMAT_OCC3_KB 4
+#endif
 constexpr int TNW = 128;   // tile columns of the wide kernel
 constexpr int LDPW = 132;  // padded stride of its column panel
 
@@ -299,8 +302,10 @@ __device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes 
     return v;
 }
 
+// (few right-hand sides: 3 waves per SIMD - the LDS footprint allows 3 workgroups per CU then;
+// +14 % at k = 4, neutral at k <= 2)
 template <bool L1, int KB, int VLD, int DCV>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (KB <= RK_KMAT_OCC3_KB ? 3 : 2))
 kmat_matmat_wide_kernel(int kind, const float* __restrict__ X1, int64_t n1, int64_t ldx1,
                         const int64_t* __restrict__ idx1, const float* __restrict__ X2, int64_t n2,
                         int64_t ldx2, const int64_t* __restrict__ idx2, int64_t d, float w,
@@ -398,17 +403,30 @@ kmat_matmat_wide_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
                 const float4 yb_n = *reinterpret_cast<const float4*>(&ys[cn][64 + tx * 4]);
                 const f32x2 yv[2][2] = {{{ya.x, ya.y}, {ya.z, ya.w}}, {{yb.x, yb.y}, {yb.z, yb.w}}};
                 const float xr[4] = {xa.x, xa.y, xa.z, xa.w};
+                // differences of two rows first, then their FMAs (keeps a v_pk_fma_f32 from issuing
+                // right behind the v_pk_add_f32 that feeds it; measured neutral - the PMC profile,
+                // VALU 58 % active / 37 % issue-stalled per 2 waves, is not explained by that)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const f32x2 xv = (f32x2)(xr[r]);
+                for (int rp = 0; rp < 2; ++rp) {
+                    f32x2 df[2][2][2];
 #pragma unroll
-                    for (int g = 0; g < 2; ++g)
+                    for (int r2 = 0; r2 < 2; ++r2) {
+                        const f32x2 xv = (f32x2)(xr[rp * 2 + r2]);
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const f32x2 df = xv - yv[g][h];
-                            if constexpr (L1) acc[r][g][h] += __builtin_elementwise_abs(df);
-                            else acc[r][g][h] = __builtin_elementwise_fma(df, df, acc[r][g][h]);
-                        }
+                        for (int g = 0; g < 2; ++g)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) df[r2][g][h] = xv - yv[g][h];
+                    }
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+                        for (int g = 0; g < 2; ++g)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                f32x2& a = acc[rp * 2 + r2][g][h];
+                                if constexpr (L1) a += __builtin_elementwise_abs(df[r2][g][h]);
+                                else a = __builtin_elementwise_fma(df[r2][g][h], df[r2][g][h], a);
+                            }
                 }
                 xa = xa_n; ya = ya_n; yb = yb_n;
             };
