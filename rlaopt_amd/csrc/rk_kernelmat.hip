@@ -193,6 +193,9 @@ kmat_matmat_finish(const T* __restrict__ part, int S, int64_t n1, int k, T scale
 // first LDS store (panel_load / panel_store): 10.0 -> 8.9 ms.
 #define RK_KMAT_PREFETCH 0
 #endif
+#ifndef RK_KMAT_SCALAR_MATH
+#define RK_KMAT_SCALAR_MATH 0
+#endif
 #ifndef RK_KMAT_OCC3_KB
 #define RK_KMAT_OCC3_KB 4
 #endif
@@ -415,7 +418,13 @@ kmat_matmat_wide_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
 #pragma unroll
                         for (int g = 0; g < 2; ++g)
 #pragma unroll
-                            for (int h = 0; h < 2; ++h) df[r2][g][h] = xv - yv[g][h];
+                            for (int h = 0; h < 2; ++h) {
+#if RK_KMAT_SCALAR_MATH  // experiment: two scalar ops instead of one packed op
+                                df[r2][g][h] = (f32x2){xv.x - yv[g][h].x, xv.y - yv[g][h].y};
+#else
+                                df[r2][g][h] = xv - yv[g][h];
+#endif
+                            }
                     }
 #pragma unroll
                     for (int r2 = 0; r2 < 2; ++r2)
@@ -425,7 +434,12 @@ kmat_matmat_wide_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
                             for (int h = 0; h < 2; ++h) {
                                 f32x2& a = acc[rp * 2 + r2][g][h];
                                 if constexpr (L1) a += __builtin_elementwise_abs(df[r2][g][h]);
+#if RK_KMAT_SCALAR_MATH
+                                else a = (f32x2){__builtin_fmaf(df[r2][g][h].x, df[r2][g][h].x, a.x),
+                                                 __builtin_fmaf(df[r2][g][h].y, df[r2][g][h].y, a.y)};
+#else
                                 else a = __builtin_elementwise_fma(df[r2][g][h], df[r2][g][h], a);
+#endif
                             }
                 }
                 xa = xa_n; ya = ya_n; yb = yb_n;
