@@ -178,14 +178,17 @@ kmat_matmat_finish(const T* __restrict__ part, int S, int64_t n1, int k, T scale
 // ------------------------------------------------------------------------------------------
 // fused product, float32: 64 x 128 tile, 4 x 8 pairs per lane, packed fp32 math
 // ------------------------------------------------------------------------------------------
-// The 4 x 4 tile above spends two VALU instructions (sub, fma) and 2/16 of a ds_read_b128 per
-// pair and feature.  Here every instruction is a v_pk_add_f32 / v_pk_fma_f32 working on two
-// pairs, and a lane owns 4 rows x (4 + 4) columns (columns tx*4.. and 64 + tx*4.., so that both
-// panel reads stay conflict-free 16-byte accesses): 1 VALU instruction and 3/32 of a
-// ds_read_b128 per pair and feature.  The V slice sits rhs-major in LDS (vs[c][column]) so that
-// the 16 lanes of a row read 16 consecutive float4 (the point-major layout of the 4 x 4 kernel
-// is a 16-way bank conflict for KB = 16), and the y update is packed over row pairs.  The 16
-// lanes that share a row are one DPP row: their sums combine with 4 v_add_f32_dpp, no LDS.
+// A lane owns 4 rows x (4 + 4) columns (columns tx*4.. and 64 + tx*4.., so that both panel reads
+// stay conflict-free 16-byte accesses): 3/32 of a ds_read_b128 per pair and feature instead of
+// the 2/16 of the 4 x 4 tile above, and every arithmetic instruction is a v_pk_add_f32 /
+// v_pk_fma_f32 on two pairs.  Measured: the packing itself is worth only 3 % (packed fp32 issues
+// at about half rate on gfx950: RK_KMAT_SCALAR_MATH=1 doubles the instruction count and loses
+// 3 %); the gain over the 4 x 4 kernel - 9 to 35 % for long rows or many right-hand sides - comes
+// from the wider register tile, from issuing all global loads of a panel before its LDS stores,
+// and from the V slice sitting rhs-major in LDS (vs[c][column]: the 16 lanes of a row read 16
+// consecutive float4; the point-major layout of the 4 x 4 kernel is a 16-way bank conflict for
+// KB = 16) with the y update packed over row pairs.  The 16 lanes that share a row are one DPP
+// row: their sums combine with 4 v_add_f32_dpp, no LDS.
 #ifndef RK_KMAT_PREFETCH
 // 1: load the next tile's panels while the current tile is computed.  Measured slower (10.1 vs
 // 8.9 ms on the ASkotch row oracle): the 38 extra live registers push the kernel over the 256
