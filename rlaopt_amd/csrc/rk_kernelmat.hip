@@ -14,6 +14,8 @@
 //                           never written.  Column segments (gridDim.y) give short-and-wide
 //                           oracle blocks (5 000 x 500 000) enough workgroups; their
 //                           partials are summed in fixed order by the finishing kernel.
+#include <stdlib.h>
+
 #include "rk_common.h"
 #include "rk_kerneltile.h"
 
@@ -634,6 +636,40 @@ static void launch_kmatmat_wide(int KB, dim3 grid, hipStream_t st, int kind, con
 #undef RK_KMW_D
 }
 
+// rk_kernelmfma.hip: the attention-shaped formulation on the matrix cores (fp32, L2 kernels)
+int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
+                        const float* X2, int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d,
+                        float w, float scale, const float* V, int k, int64_t ldv, int64_t S,
+                        int64_t tiles_per_seg, float* norms, float* part, float* Y, int64_t ldy,
+                        int accumulate, hipStream_t st);
+
+// Opt-in at run time (environment RK_KMAT_MFMA=1, read per call): the formulation is correct and
+// tested, but as built - one workgroup per CU (134 KB of LDS), accurate expf on the VALU - it
+// reaches 187 Gpair/s at d = 64 against 333 for the VALU kernel (PMC: matrix cores 25 % busy,
+// VALU 24 %, waves waiting 55 %: nothing overlaps at one wave per SIMD).  DESIGN.md section 9.
+static bool kmat_use_mfma(bool is_f32, int kind, const void* ell_vec, int64_t d, int64_t n1, int64_t n2) {
+    if (!(is_f32 && kind != RK_LAPLACE && ell_vec == nullptr && d <= 64 && n2 >= 128 && n1 >= 1))
+        return false;
+    const char* e = getenv("RK_KMAT_MFMA");
+    return e != nullptr && e[0] == '1';
+}
+
+static KMPlan plan_kmatmat_mfma(int64_t n1, int64_t n2) {
+    const int64_t row_blocks = ceil_div(n1, 128);
+    const int64_t ntile = ceil_div(n2, 128);
+    int64_t S = ceil_div(1024, row_blocks);  // one workgroup per CU is resident: >= 4 rounds
+    if (S > ntile / 4) S = ntile / 4;        // >= 4 column tiles per workgroup
+    if (S < 1) S = 1;
+    KMPlan p;
+    p.tiles_per_seg = ceil_div(ntile, S);
+    p.S = ceil_div(ntile, p.tiles_per_seg);
+    return p;
+}
+
+static size_t kmat_norms_offset(int64_t S, int64_t n1, int64_t k) {  // norms sit behind the partials
+    return round_up((size_t)(S > 1 ? S : 0) * n1 * k * sizeof(float), 256);
+}
+
 template <typename T>
 static int kmatmat_impl(int kind, const T* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
                         const T* X2, int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d,
@@ -641,6 +677,26 @@ static int kmatmat_impl(int kind, const T* X1, int64_t n1, int64_t ldx1, const i
                         int64_t ldv, T* Y, int64_t ldy, int accumulate, void* ws, size_t ws_bytes,
                         hipStream_t st) {
     const T w = ell_vec ? T(1) : T(1.0 / ell);
+    if constexpr (sizeof(T) == 4) {
+        if (kmat_use_mfma(true, kind, ell_vec, d, n1, n2)) {
+            const KMPlan pm = plan_kmatmat_mfma(n1, n2);
+            const size_t off = kmat_norms_offset(pm.S, n1, k);
+            const size_t need = off + (size_t)(n1 + n2) * sizeof(float);
+            if (ws == nullptr || ws_bytes < need) {
+                set_error("rk_kernel_matmat: workspace %zu B < required %zu B", ws_bytes, need);
+                return RK_ERR_WORKSPACE;
+            }
+            float* partm = pm.S > 1 ? static_cast<float*>(ws) : nullptr;
+            float* norms = reinterpret_cast<float*>(static_cast<char*>(ws) + off);
+            int rcm = launch_kmatmat_mfma(kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d, (float)w,
+                                          (float)scale, V, (int)k, ldv, pm.S, pm.tiles_per_seg, norms,
+                                          partm, Y, ldy, accumulate, st);
+            if (rcm != RK_OK || partm == nullptr) return rcm;
+            hipLaunchKernelGGL((kmat_matmat_finish<T>), dim3((unsigned)ceil_div(n1 * k, 256)), dim3(256),
+                               0, st, partm, (int)pm.S, n1, (int)k, (T)scale, Y, ldy, accumulate);
+            return launch_status("rk_kernel_matmat(finish)");
+        }
+    }
     const KMPlan p = plan_kmatmat(n1, n2, kmat_tile_cols(sizeof(T) == 4, d, k));
     T* part = nullptr;
     if (p.S > 1) {
@@ -729,7 +785,13 @@ extern "C" size_t rk_kernel_matmat_ws_bytes(int dtype, int64_t n1, int64_t n2, i
     // the tile shape depends on d (not an argument here): size for the larger of the two plans
     const KMPlan pa = plan_kmatmat(n1, n2, TN), pb = plan_kmatmat(n1, n2, TNW);
     const int64_t S = pa.S > pb.S ? pa.S : pb.S;
-    return S > 1 ? (size_t)S * n1 * k * (dtype == RK_F32 ? 4 : 8) : 0;
+    size_t bytes = S > 1 ? (size_t)S * n1 * k * (dtype == RK_F32 ? 4 : 8) : 0;
+    if (dtype == RK_F32) {  // the matrix-core path: its partials + the |x|^2 of both point sets
+        const KMPlan pm = plan_kmatmat_mfma(n1, n2);
+        const size_t m = kmat_norms_offset(pm.S, n1, k) + (size_t)(n1 + n2) * sizeof(float);
+        if (m > bytes) bytes = m;
+    }
+    return bytes;
 }
 
 extern "C" int rk_kernel_matmat(int dtype, int kind, const void* X1, int64_t n1, int64_t ldx1,

@@ -1,0 +1,241 @@
+// Fused kernel-matrix product on the matrix cores (float32, L2 kernels, d <= 64, k <= 16):
+//
+//     Y[i][c] = scale * sum_j kappa(|x_i - y_j|^2) V[j][c]
+//
+// as two chained exact-fp32 MFMA products per 128 x 128 tile - the shape of an attention block:
+//     S^T = X2_tile X1_block^T                 (v_mfma_f32_32x32x2_f32 over the d features)
+//     P   = kappa(|x_i|^2 + |y_j|^2 - 2 S)     (on the accumulator registers)
+//     Y^T += V_tile^T P^T                      (second MFMA; P is fed from those same registers:
+//                                               with S computed transposed, a lane's accumulator
+//                                               element v is exactly the B operand B[k = lane/32]
+//                                               [n = lane%32] of step v of the second product)
+// The VALU-formulated kernels (rk_kernelmat.hip) are bound by 2 vector instructions per pair and
+// feature; here the d-long contraction runs on the MFMA pipe (64 flop/clk/SIMD, twice the scalar
+// FMA rate, and 2 instead of 3 flops per pair and feature) and the VALU only evaluates kappa.
+// |x|^2 + |y|^2 - 2 x.y cancels to ~1e-7 absolute in fp32 - inside the fp32 tolerance (1e-4);
+// float64 keeps the direct (x - y)^2 kernels for its 1e-8 tolerance, and so does Laplace (L1).
+//
+// Workgroup = 4 waves (2 x 2), tile = 128 points of X2 (j) x 128 points of X1 (i); a wave owns
+// 64 j x 64 i = 2 x 2 MFMA blocks.  The X1 block stays in LDS (k-major) for the whole kernel; X2
+// tiles, V tiles and |y|^2 are double-buffered (global -> registers during the MFMAs of the
+// previous tile -> LDS).  Per wave Y^T lives in 2 accumulators (32 rhs x 32 i each) for all
+// tiles; at the end the two waves that share an i-range add theirs through LDS (fixed order).
+#include "rk_common.h"
+#include "rk_kerneltile.h"
+
+namespace rk {
+
+constexpr int MF_T = 128;    // tile edge (points)
+constexpr int MF_D = 64;     // features staged (d <= MF_D)
+constexpr int MF_LD = 130;   // LDS stride of the k-major panels (conflict-free transposing store)
+constexpr int MF_LDV = 33;   // stride of the V tile rows (rhs index contiguous, padded to 32)
+
+typedef float mf_acc __attribute__((ext_vector_type(16)));
+
+// |row|^2 of gathered rows: out[p] = sum_c X[row(p)][c]^2
+__global__ void __launch_bounds__(256)
+row_norms_kernel(const float* __restrict__ X, int64_t ldx, const int64_t* __restrict__ idx, int64_t n,
+                 int64_t d, float* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float* row = X + (idx ? idx[p] : p) * ldx;
+    float s = 0.f;
+    for (int64_t c = 0; c < d; ++c) s += row[c] * row[c];
+    out[p] = s;
+}
+
+// element v of a 32x32 accumulator sits in row (v&3) + 8*(v>>2) + 4*(lane/32), column lane%32
+__device__ __forceinline__ int mf_row(int v, int lk) { return (v & 3) + 8 * (v >> 2) + 4 * lk; }
+
+__global__ void __launch_bounds__(256)
+kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int64_t ldx1,
+                        const int64_t* __restrict__ idx1, const float* __restrict__ X2, int64_t n2,
+                        int64_t ldx2, const int64_t* __restrict__ idx2, int64_t d, float w,
+                        float scale, const float* __restrict__ nx, const float* __restrict__ ny,
+                        const float* __restrict__ V, int k, int64_t ldv, int64_t tiles_per_seg,
+                        float* __restrict__ part, float* __restrict__ Y, int64_t ldy, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float (*S1)[MF_LD] = reinterpret_cast<float (*)[MF_LD]>(smem);                       // [MF_D][MF_LD]
+    float (*S2)[MF_D][MF_LD] = reinterpret_cast<float (*)[MF_D][MF_LD]>(smem + MF_D * MF_LD);  // [2]
+    float (*VS)[MF_T][MF_LDV] =
+        reinterpret_cast<float (*)[MF_T][MF_LDV]>(smem + 3 * MF_D * MF_LD);               // [2]
+    float (*NY)[MF_T] = reinterpret_cast<float (*)[MF_T]>(smem + 3 * MF_D * MF_LD + 2 * MF_T * MF_LDV);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;  // j- and i-offset of this wave
+    const int lk = lane >> 5, li = lane & 31;
+    const int64_t i0 = (int64_t)blockIdx.x * MF_T;
+    const int64_t ntile = (n2 + MF_T - 1) / MF_T;
+    const int64_t t_lo = (int64_t)blockIdx.y * tiles_per_seg;
+    const int64_t t_hi = (t_lo + tiles_per_seg < ntile) ? t_lo + tiles_per_seg : ntile;
+    const int dpad = (int)((d + 1) & ~(int64_t)1);  // MFMA k step is 2; features >= d are zero in LDS
+
+    // ---- staging helpers: thread -> point tid/2, features (tid%2)*32 .. +31 -------------------
+    const int sp = tid >> 1, sf = (tid & 1) * 32;
+    float xr[32];
+    auto load_panel = [&](const float* __restrict__ X, int64_t n, int64_t ldx,
+                          const int64_t* __restrict__ idx, int64_t p0) {
+        const int64_t p = p0 + sp;
+        const float* row = (p < n) ? X + (idx ? idx[p] : p) * ldx : nullptr;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) xr[u] = (row != nullptr && sf + u < d) ? row[sf + u] : 0.f;
+    };
+    auto store_panel = [&](float (*dst)[MF_LD]) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u) dst[sf + u][sp] = xr[u];
+    };
+    float vr[16], nyr;
+    auto load_v = [&](int64_t j0) {  // thread -> point tid/2, rhs (tid%2)*16 .. +15 (zero past k)
+        const int64_t j = j0 + sp;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int c = (tid & 1) * 16 + u;
+            vr[u] = (j < n2 && c < k) ? V[j * ldv + c] : 0.f;
+        }
+        nyr = (tid < MF_T && j0 + tid < n2) ? ny[j0 + tid] : 0.f;
+    };
+    auto store_v = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) VS[buf][sp][(tid & 1) * 16 + u] = vr[u];
+        if (tid < MF_T) NY[buf][tid] = nyr;
+    };
+
+    // X1 block: resident for the whole kernel
+    load_panel(X1, n1, ldx1, idx1, i0);
+    store_panel(S1);
+    float nxr[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int64_t i = i0 + wn + b * 32 + li;
+        nxr[b] = i < n1 ? nx[i] : 0.f;
+    }
+    mf_acc yacc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) yacc[b][v] = 0.f;
+
+    if (t_lo < t_hi) {
+        load_panel(X2, n2, ldx2, idx2, t_lo * MF_T);
+        load_v(t_lo * MF_T);
+        store_panel(S2[0]);
+        store_v(0);
+    }
+    int buf = 0;
+    for (int64_t t = t_lo; t < t_hi; ++t) {
+        __syncthreads();  // tile t is in LDS (and, first time round, the X1 block)
+        const bool more = t + 1 < t_hi;
+        if (more) {
+            load_panel(X2, n2, ldx2, idx2, (t + 1) * MF_T);
+            load_v((t + 1) * MF_T);
+        }
+        // ---- S^T = X2_tile X1^T over the features ------------------------------------------
+        mf_acc acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+        for (int ks = 0; ks < dpad; ks += 2) {
+            float af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = S2[buf][ks + lk][wm + a * 32 + li];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b] = S1[ks + lk][wn + b * 32 + li];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        // ---- P = kappa(|x|^2 + |y|^2 - 2 S) in place; Y^T += V^T P^T ---------------------------
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float nyv = NY[buf][wm + a * 32 + mf_row(v, lk)];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float s = nxr[b] + nyv - 2.f * acc[a][b][v];
+                    s = s > 0.f ? s : 0.f;
+                    acc[a][b][v] = kernel_value<float>(kind, s, w);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                // A operand of step v: V[j = row v of this lane half][c = lane%32]
+                const float av = VS[buf][wm + a * 32 + mf_row(v, lk)][li];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    yacc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, acc[a][b][v], yacc[b], 0, 0, 0);
+            }
+        }
+        if (more) {
+            store_panel(S2[buf ^ 1]);
+            store_v(buf ^ 1);
+        }
+        buf ^= 1;
+    }
+    // ---- combine the two waves of each i-range, write ------------------------------------------
+    __syncthreads();  // every wave is done with the panels: reuse S2[0] as [4 waves][16 c][64 i]
+    float* yl = &S2[0][0][0];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {  // rhs c = mf_row(v, lk) < 16 for v < 8
+            const int c = mf_row(v, lk);
+            yl[(wave * 16 + c) * 64 + b * 32 + li] = yacc[b][v];
+        }
+    __syncthreads();
+    for (int e = tid; e < MF_T * k; e += 256) {
+        const int il = e / k, c = e - il * k;  // il: row within the block
+        const int wcol = il >> 6;              // waves wcol (j half 0) and wcol + 2 (j half 1)
+        const float sum = yl[(wcol * 16 + c) * 64 + (il & 63)] + yl[((wcol + 2) * 16 + c) * 64 + (il & 63)];
+        const int64_t i = i0 + il;
+        if (i >= n1) continue;
+        if (part != nullptr) {
+            part[((int64_t)blockIdx.y * n1 + i) * k + c] = sum;
+        } else {
+            const float o = scale * sum;
+            if (accumulate) Y[i * ldy + c] += o;
+            else Y[i * ldy + c] = o;
+        }
+    }
+}
+
+constexpr size_t MF_SMEM_BYTES =
+    sizeof(float) * (3 * MF_D * MF_LD + 2 * MF_T * MF_LDV + 2 * MF_T);  // S1 + S2[2] + VS[2] + NY[2]
+
+// launch (float32 only): norms of both point sets into `norms` (n1 + n2 floats), then the tiles
+int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
+                        const float* X2, int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d,
+                        float w, float scale, const float* V, int k, int64_t ldv, int64_t S,
+                        int64_t tiles_per_seg, float* norms, float* part, float* Y, int64_t ldy,
+                        int accumulate, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kmat_matmat_mfma_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)MF_SMEM_BYTES) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("rk_kernel_matmat: cannot reserve %zu bytes of LDS", MF_SMEM_BYTES);
+            return RK_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    float* nxp = norms;
+    float* nyp = norms + n1;
+    hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)ceil_div(n1, 256)), dim3(256), 0, st, X1, ldx1,
+                       idx1, n1, d, nxp);
+    hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)ceil_div(n2, 256)), dim3(256), 0, st, X2, ldx2,
+                       idx2, n2, d, nyp);
+    dim3 grid((unsigned)ceil_div(n1, MF_T), (unsigned)S);
+    hipLaunchKernelGGL(kmat_matmat_mfma_kernel, grid, dim3(256), MF_SMEM_BYTES, st, kind, X1, n1, ldx1,
+                       idx1, X2, n2, ldx2, idx2, d, w, scale, nxp, nyp, V, k, ldv, tiles_per_seg, part,
+                       Y, ldy, accumulate);
+    return launch_status("rk_kernel_matmat(mfma)");
+}
+
+}  // namespace rk

@@ -322,3 +322,28 @@ def test_normal_pass_unsupported_shapes(be):
                           torch.ones(3, dtype=torch.float64, device=dev())) is None
     A5 = torch.randn(100, 66, dtype=torch.float32, device=dev())  # n not a multiple of 4
     assert be.normal_pass(A5, torch.randn(66, 1, device=dev()), torch.randn(100, 1, device=dev()), c) is None
+
+
+@pytest.mark.parametrize("n1,n2,d,k", [(129, 1000, 50, 10), (300, 515, 64, 1), (64, 128, 33, 16), (500, 2100, 8, 4)])
+def test_kernel_matmat_matrix_core_formulation(be, monkeypatch, n1, n2, d, k):
+    """RK_KMAT_MFMA=1 (opt-in): S = X2 X1^T on the fp32 matrix cores, |x|^2 + |y|^2 - 2 S, kappa on
+    the accumulators, Y^T += V^T P^T - against the oracle and the default (direct-difference) path,
+    with and without index gathers."""
+    dt = torch.float32
+    gen = torch.Generator().manual_seed(n1 + n2 + d)
+    X1 = torch.randn(n1, d, dtype=dt, generator=gen) / d**0.5
+    X2 = torch.randn(n2, d, dtype=dt, generator=gen) / d**0.5
+    V = torch.randn(n2, k, dtype=dt, generator=gen)
+    blk = torch.randperm(n2, generator=gen)[: min(n1, 97)]
+    for kind in ("rbf", "matern32"):
+        want = ok.kernel_matmat(kind, X1.double(), X2.double(), 0.8, V.double(), 1.5)
+        want_g = ok.kernel_matmat(kind, X2.double(), X2.double(), 0.8, V.double(), 1.5, idx1=blk)
+        base = be.kernel_matmat(kind, X1.to(dev()), X2.to(dev()), 0.8, V.to(dev()), scale=1.5)
+        monkeypatch.setenv("RK_KMAT_MFMA", "1")
+        got = be.kernel_matmat(kind, X1.to(dev()), X2.to(dev()), 0.8, V.to(dev()), scale=1.5)
+        got_g = be.kernel_matmat(kind, X2.to(dev()), X2.to(dev()), 0.8, V.to(dev()), scale=1.5, idx1=blk.to(dev()))
+        monkeypatch.delenv("RK_KMAT_MFMA")
+        assert rel_err(got.cpu(), want) < LIM[dt]
+        assert rel_err(got_g.cpu(), want_g) < LIM[dt]
+        assert rel_err(got.cpu(), base.cpu().double()) < LIM[dt]
+        assert not torch.equal(got, base)  # (a different kernel really ran)
