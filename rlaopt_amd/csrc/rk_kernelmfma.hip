@@ -16,10 +16,12 @@
 // float64 keeps the direct (x - y)^2 kernels for its 1e-8 tolerance, and so does Laplace (L1).
 //
 // Workgroup = 4 waves (2 x 2), tile = 128 points of X2 (j) x 128 points of X1 (i); a wave owns
-// 64 j x 64 i = 2 x 2 MFMA blocks.  The X1 block stays in LDS (k-major) for the whole kernel; X2
-// tiles, V tiles and |y|^2 are double-buffered (global -> registers during the MFMAs of the
-// previous tile -> LDS).  Per wave Y^T lives in 2 accumulators (32 rhs x 32 i each) for all
-// tiles; at the end the two waves that share an i-range add theirs through LDS (fixed order).
+// 64 j x 64 i = 2 x 2 MFMA blocks.  The X1 block stays in LDS (k-major) for the whole kernel; the
+// X2 tile, V tile and |y|^2 of the next tile are fetched into registers during the MFMAs of the
+// current one and stored to the (single) LDS buffers between two barriers: 76 KB of LDS, two
+// workgroups per CU, so one workgroup's MFMAs overlap the other's kappa evaluation and waits.
+// Per wave Y^T lives in 2 accumulators (32 rhs x 32 i each) for all tiles; at the end the two
+// waves that share an i-range add theirs through LDS (fixed order).
 #include "rk_common.h"
 #include "rk_kerneltile.h"
 
@@ -28,7 +30,7 @@ namespace rk {
 constexpr int MF_T = 128;    // tile edge (points)
 constexpr int MF_D = 64;     // features staged (d <= MF_D)
 constexpr int MF_LD = 130;   // LDS stride of the k-major panels (conflict-free transposing store)
-constexpr int MF_LDV = 33;   // stride of the V tile rows (rhs index contiguous, padded to 32)
+constexpr int MF_LDV = 17;   // stride of the V tile rows (16 rhs, contiguous)
 
 typedef float mf_acc __attribute__((ext_vector_type(16)));
 
@@ -47,7 +49,15 @@ row_norms_kernel(const float* __restrict__ X, int64_t ldx, const int64_t* __rest
 // element v of a 32x32 accumulator sits in row (v&3) + 8*(v>>2) + 4*(lane/32), column lane%32
 __device__ __forceinline__ int mf_row(int v, int lk) { return (v & 3) + 8 * (v >> 2) + 4 * lk; }
 
-__global__ void __launch_bounds__(256)
+// kappa on the accumulators: the RBF instantiation is one multiply and one v_exp_f32
+template <bool RBF>
+__device__ __forceinline__ float mf_kappa(int kind, float s, float w, float rbf_c) {
+    if constexpr (RBF) return __builtin_amdgcn_exp2f(s * rbf_c);  // exp(-s w^2 / 2), c = -w^2 log2(e) / 2
+    else return kernel_value<float>(kind, s, w);
+}
+
+template <bool RBF, int VLD>
+__global__ void __launch_bounds__(256, 2)
 kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int64_t ldx1,
                         const int64_t* __restrict__ idx1, const float* __restrict__ X2, int64_t n2,
                         int64_t ldx2, const int64_t* __restrict__ idx2, int64_t d, float w,
@@ -55,11 +65,11 @@ kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
                         const float* __restrict__ V, int k, int64_t ldv, int64_t tiles_per_seg,
                         float* __restrict__ part, float* __restrict__ Y, int64_t ldy, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float (*S1)[MF_LD] = reinterpret_cast<float (*)[MF_LD]>(smem);                       // [MF_D][MF_LD]
-    float (*S2)[MF_D][MF_LD] = reinterpret_cast<float (*)[MF_D][MF_LD]>(smem + MF_D * MF_LD);  // [2]
-    float (*VS)[MF_T][MF_LDV] =
-        reinterpret_cast<float (*)[MF_T][MF_LDV]>(smem + 3 * MF_D * MF_LD);               // [2]
-    float (*NY)[MF_T] = reinterpret_cast<float (*)[MF_T]>(smem + 3 * MF_D * MF_LD + 2 * MF_T * MF_LDV);
+    float (*S1)[MF_LD] = reinterpret_cast<float (*)[MF_LD]>(smem);                   // [MF_D][MF_LD]
+    float (*S2)[MF_LD] = reinterpret_cast<float (*)[MF_LD]>(smem + MF_D * MF_LD);     // [MF_D][MF_LD]
+    float (*VS)[MF_LDV] = reinterpret_cast<float (*)[MF_LDV]>(smem + 2 * MF_D * MF_LD);  // [MF_T][MF_LDV]
+    float* NY = smem + 2 * MF_D * MF_LD + MF_T * MF_LDV;                              // [MF_T]
+    const float rbf_c = -0.5f * w * w * 1.4426950408889634f;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -78,27 +88,45 @@ kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
                           const int64_t* __restrict__ idx, int64_t p0) {
         const int64_t p = p0 + sp;
         const float* row = (p < n) ? X + (idx ? idx[p] : p) * ldx : nullptr;
+        if constexpr (VLD == 1) {
 #pragma unroll
-        for (int u = 0; u < 32; ++u) xr[u] = (row != nullptr && sf + u < d) ? row[sf + u] : 0.f;
+            for (int u = 0; u < 32; ++u) xr[u] = (row != nullptr && sf + u < d) ? row[sf + u] : 0.f;
+        } else {  // rows are VLD-float aligned and d is a multiple of VLD
+#pragma unroll
+            for (int u = 0; u < 32; u += VLD) {
+                if (row != nullptr && sf + u < d) {
+                    if constexpr (VLD == 4) {
+                        const float4 q = *reinterpret_cast<const float4*>(row + sf + u);
+                        xr[u] = q.x; xr[u + 1] = q.y; xr[u + 2] = q.z; xr[u + 3] = q.w;
+                    } else {
+                        const float2 q = *reinterpret_cast<const float2*>(row + sf + u);
+                        xr[u] = q.x; xr[u + 1] = q.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VLD; ++e) xr[u + e] = 0.f;
+                }
+            }
+        }
     };
     auto store_panel = [&](float (*dst)[MF_LD]) {
 #pragma unroll
         for (int u = 0; u < 32; ++u) dst[sf + u][sp] = xr[u];
     };
-    float vr[16], nyr;
-    auto load_v = [&](int64_t j0) {  // thread -> point tid/2, rhs (tid%2)*16 .. +15 (zero past k)
+    float vr[8], nyr;
+    auto load_v = [&](int64_t j0) {  // thread -> point tid/2, rhs (tid%2)*8 .. +7 (zero past k)
         const int64_t j = j0 + sp;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int c = (tid & 1) * 16 + u;
+        for (int u = 0; u < 8; ++u) {
+            const int c = (tid & 1) * 8 + u;
             vr[u] = (j < n2 && c < k) ? V[j * ldv + c] : 0.f;
         }
         nyr = (tid < MF_T && j0 + tid < n2) ? ny[j0 + tid] : 0.f;
     };
-    auto store_v = [&](int buf) {
+    auto store_v = [&]() {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) VS[buf][sp][(tid & 1) * 16 + u] = vr[u];
-        if (tid < MF_T) NY[buf][tid] = nyr;
+        for (int u = 0; u < 8; ++u) VS[sp][(tid & 1) * 8 + u] = vr[u];
+        if (tid < MF_T) NY[tid] = nyr;
     };
 
     // X1 block: resident for the whole kernel
@@ -110,23 +138,35 @@ kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
         const int64_t i = i0 + wn + b * 32 + li;
         nxr[b] = i < n1 ? nx[i] : 0.f;
     }
-    mf_acc yacc[2];
+    // two-level sums: the MFMA accumulators are folded into ytot every 16 tiles (2 048 columns), so
+    // the float32 rounding of a 30 000-column segment grows like a pairwise, not a running, sum
+    mf_acc yacc[2], ytot[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) yacc[b][v] = 0.f;
+        for (int v = 0; v < 16; ++v) {
+            yacc[b][v] = 0.f;
+            ytot[b][v] = 0.f;
+        }
 
     if (t_lo < t_hi) {
         load_panel(X2, n2, ldx2, idx2, t_lo * MF_T);
         load_v(t_lo * MF_T);
-        store_panel(S2[0]);
-        store_v(0);
     }
-    int buf = 0;
     for (int64_t t = t_lo; t < t_hi; ++t) {
+        if (((t - t_lo) & 15) == 15) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                ytot[b] += yacc[b];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) yacc[b][v] = 0.f;
+            }
+        }
+        __syncthreads();  // every wave is done reading the previous tile
+        store_panel(S2);
+        store_v();
         __syncthreads();  // tile t is in LDS (and, first time round, the X1 block)
-        const bool more = t + 1 < t_hi;
-        if (more) {
+        if (t + 1 < t_hi) {  // next tile: global loads in flight during this tile's MFMAs
             load_panel(X2, n2, ldx2, idx2, (t + 1) * MF_T);
             load_v((t + 1) * MF_T);
         }
@@ -138,10 +178,11 @@ kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+#pragma unroll 2
         for (int ks = 0; ks < dpad; ks += 2) {
             float af[2], bf[2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) af[a] = S2[buf][ks + lk][wm + a * 32 + li];
+            for (int a = 0; a < 2; ++a) af[a] = S2[ks + lk][wm + a * 32 + li];
 #pragma unroll
             for (int b = 0; b < 2; ++b) bf[b] = S1[ks + lk][wn + b * 32 + li];
 #pragma unroll
@@ -155,38 +196,33 @@ kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
         for (int a = 0; a < 2; ++a) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const float nyv = NY[buf][wm + a * 32 + mf_row(v, lk)];
+                const float nyv = NY[wm + a * 32 + mf_row(v, lk)];
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     float s = nxr[b] + nyv - 2.f * acc[a][b][v];
                     s = s > 0.f ? s : 0.f;
-                    acc[a][b][v] = kernel_value<float>(kind, s, w);
+                    acc[a][b][v] = mf_kappa<RBF>(kind, s, w, rbf_c);
                 }
             }
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                // A operand of step v: V[j = row v of this lane half][c = lane%32]
-                const float av = VS[buf][wm + a * 32 + mf_row(v, lk)][li];
+                // A operand of step v: V[j = row v of this lane half][c = lane%32] (zero for c >= 16)
+                const float av = li < 16 ? VS[wm + a * 32 + mf_row(v, lk)][li] : 0.f;
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
                     yacc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, acc[a][b][v], yacc[b], 0, 0, 0);
             }
         }
-        if (more) {
-            store_panel(S2[buf ^ 1]);
-            store_v(buf ^ 1);
-        }
-        buf ^= 1;
     }
     // ---- combine the two waves of each i-range, write ------------------------------------------
-    __syncthreads();  // every wave is done with the panels: reuse S2[0] as [4 waves][16 c][64 i]
-    float* yl = &S2[0][0][0];
+    __syncthreads();  // every wave is done with the panels: reuse S2 as [4 waves][16 c][64 i]
+    float* yl = &S2[0][0];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int v = 0; v < 8; ++v) {  // rhs c = mf_row(v, lk) < 16 for v < 8
             const int c = mf_row(v, lk);
-            yl[(wave * 16 + c) * 64 + b * 32 + li] = yacc[b][v];
+            yl[(wave * 16 + c) * 64 + b * 32 + li] = ytot[b][v] + yacc[b][v];
         }
     __syncthreads();
     for (int e = tid; e < MF_T * k; e += 256) {
@@ -206,7 +242,7 @@ kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
 }
 
 constexpr size_t MF_SMEM_BYTES =
-    sizeof(float) * (3 * MF_D * MF_LD + 2 * MF_T * MF_LDV + 2 * MF_T);  // S1 + S2[2] + VS[2] + NY[2]
+    sizeof(float) * (2 * MF_D * MF_LD + MF_T * MF_LDV + MF_T);  // S1 + S2 + VS + NY
 
 // launch (float32 only): norms of both point sets into `norms` (n1 + n2 floats), then the tiles
 int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
@@ -214,27 +250,48 @@ int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, con
                         float w, float scale, const float* V, int k, int64_t ldv, int64_t S,
                         int64_t tiles_per_seg, float* norms, float* part, float* Y, int64_t ldy,
                         int accumulate, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kmat_matmat_mfma_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)MF_SMEM_BYTES) != hipSuccess) {
-            (void)hipGetLastError();
-            set_error("rk_kernel_matmat: cannot reserve %zu bytes of LDS", MF_SMEM_BYTES);
-            return RK_ERR_LAUNCH;
-        }
-        attr_set = true;
-    }
     float* nxp = norms;
     float* nyp = norms + n1;
     hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)ceil_div(n1, 256)), dim3(256), 0, st, X1, ldx1,
                        idx1, n1, d, nxp);
     hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)ceil_div(n2, 256)), dim3(256), 0, st, X2, ldx2,
                        idx2, n2, d, nyp);
+    auto align = [&](const float* X, int64_t ldx) {  // widest vector load of a row piece
+        const uintptr_t a = reinterpret_cast<uintptr_t>(X);
+        if (a % 16 == 0 && ldx % 4 == 0 && d % 4 == 0) return 4;
+        if (a % 8 == 0 && ldx % 2 == 0 && d % 2 == 0) return 2;
+        return 1;
+    };
+    const int v1 = align(X1, ldx1), v2 = align(X2, ldx2);
+    const int vld = v1 < v2 ? v1 : v2;
     dim3 grid((unsigned)ceil_div(n1, MF_T), (unsigned)S);
-    hipLaunchKernelGGL(kmat_matmat_mfma_kernel, grid, dim3(256), MF_SMEM_BYTES, st, kind, X1, n1, ldx1,
-                       idx1, X2, n2, ldx2, idx2, d, w, scale, nxp, nyp, V, k, ldv, tiles_per_seg, part,
-                       Y, ldy, accumulate);
+#define RK_MF(RBFV, VLDV)                                                                          \
+    do {                                                                                           \
+        static bool attr_set = false;                                                              \
+        if (!attr_set) {                                                                           \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kmat_matmat_mfma_kernel<RBFV, VLDV>), \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,                    \
+                                    (int)MF_SMEM_BYTES) != hipSuccess) {                           \
+                (void)hipGetLastError();                                                           \
+                set_error("rk_kernel_matmat: cannot reserve %zu bytes of LDS", MF_SMEM_BYTES);     \
+                return RK_ERR_LAUNCH;                                                              \
+            }                                                                                      \
+            attr_set = true;                                                                       \
+        }                                                                                          \
+        hipLaunchKernelGGL((kmat_matmat_mfma_kernel<RBFV, VLDV>), grid, dim3(256), MF_SMEM_BYTES, st, \
+                           kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d, w, scale, nxp, nyp, V, k, \
+                           ldv, tiles_per_seg, part, Y, ldy, accumulate);                          \
+    } while (0)
+    if (kind == RK_RBF) {
+        if (vld == 4) RK_MF(true, 4);
+        else if (vld == 2) RK_MF(true, 2);
+        else RK_MF(true, 1);
+    } else {
+        if (vld == 4) RK_MF(false, 4);
+        else if (vld == 2) RK_MF(false, 2);
+        else RK_MF(false, 1);
+    }
+#undef RK_MF
     return launch_status("rk_kernel_matmat(mfma)");
 }
 

@@ -326,9 +326,9 @@ def test_normal_pass_unsupported_shapes(be):
 
 @pytest.mark.parametrize("n1,n2,d,k", [(129, 1000, 50, 10), (300, 515, 64, 1), (64, 128, 33, 16), (500, 2100, 8, 4)])
 def test_kernel_matmat_matrix_core_formulation(be, monkeypatch, n1, n2, d, k):
-    """RK_KMAT_MFMA=1 (opt-in): S = X2 X1^T on the fp32 matrix cores, |x|^2 + |y|^2 - 2 S, kappa on
-    the accumulators, Y^T += V^T P^T - against the oracle and the default (direct-difference) path,
-    with and without index gathers."""
+    """The matrix-core formulation (default for float32 L2 kernels with d <= 64: S = X2 X1^T on the
+    fp32 MFMA, |x|^2 + |y|^2 - 2 S, kappa on the accumulators, Y^T += V^T P^T) against the oracle
+    and against the direct-difference kernels (RK_KMAT_MFMA=0), with and without index gathers."""
     dt = torch.float32
     gen = torch.Generator().manual_seed(n1 + n2 + d)
     X1 = torch.randn(n1, d, dtype=dt, generator=gen) / d**0.5
@@ -338,11 +338,11 @@ def test_kernel_matmat_matrix_core_formulation(be, monkeypatch, n1, n2, d, k):
     for kind in ("rbf", "matern32"):
         want = ok.kernel_matmat(kind, X1.double(), X2.double(), 0.8, V.double(), 1.5)
         want_g = ok.kernel_matmat(kind, X2.double(), X2.double(), 0.8, V.double(), 1.5, idx1=blk)
+        monkeypatch.setenv("RK_KMAT_MFMA", "0")
         base = be.kernel_matmat(kind, X1.to(dev()), X2.to(dev()), 0.8, V.to(dev()), scale=1.5)
-        monkeypatch.setenv("RK_KMAT_MFMA", "1")
+        monkeypatch.delenv("RK_KMAT_MFMA")
         got = be.kernel_matmat(kind, X1.to(dev()), X2.to(dev()), 0.8, V.to(dev()), scale=1.5)
         got_g = be.kernel_matmat(kind, X2.to(dev()), X2.to(dev()), 0.8, V.to(dev()), scale=1.5, idx1=blk.to(dev()))
-        monkeypatch.delenv("RK_KMAT_MFMA")
         assert rel_err(got.cpu(), want) < LIM[dt]
         assert rel_err(got_g.cpu(), want_g) < LIM[dt]
         assert rel_err(got.cpu(), base.cpu().double()) < LIM[dt]

@@ -112,7 +112,9 @@ def test_fullsize_fused_product_properties(be, full_problem):
     # (2) symmetry of the bilinear form  u^T (K v) == v^T (K u)
     a = (ud.double() * Kv.double()).sum(0)
     b = (vd.double() * Ku.double()).sum(0)
-    assert float(((a - b).abs() / a.abs().clamp_min(1.0)).max()) < 1e-4
+    # (float32 sums of 200 000 signed terms: the form's condition number sum|u_i (Kv)_i| / |u^T K v|
+    #  is ~1e4 here, so agreement to a few 1e-4 is what float32 accumulation allows)
+    assert float(((a - b).abs() / a.abs().clamp_min(1.0)).max()) < 5e-4
     # (3) linearity  K (2u - 3v) == 2 K u - 3 K v
     lin = be.kernel_matmat("rbf", Xd, Xd, 1.0, 2 * ud - 3 * vd)
     ref = 2 * Ku - 3 * Kv
