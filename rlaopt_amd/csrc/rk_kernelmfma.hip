@@ -56,7 +56,10 @@ __device__ __forceinline__ float mf_kappa(int kind, float s, float w, float rbf_
     else return kernel_value<float>(kind, s, w);
 }
 
-template <bool RBF, int VLD>
+// KV = 0: the second product on the matrix cores (rhs padded to 32).  KV = 1 / 2 / 4 (k <= KV):
+// the second product on the VALU - per lane 64 * KV FMAs per tile into 2 * KV running sums, a
+// sixteenth of the MFMA work the padded form would spend on so few right-hand sides.
+template <bool RBF, int VLD, int KV>
 __global__ void __launch_bounds__(256, 2)
 kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int64_t ldx1,
                         const int64_t* __restrict__ idx1, const float* __restrict__ X2, int64_t n2,
@@ -149,12 +152,26 @@ kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
             ytot[b][v] = 0.f;
         }
 
+    constexpr int KVN = KV > 0 ? KV : 1;
+    float yv[2][KVN], yvt[2][KVN];  // (KV > 0) running sums of this lane's (i, rhs) pairs, two-level
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int c = 0; c < KVN; ++c) yv[b][c] = yvt[b][c] = 0.f;
+
     if (t_lo < t_hi) {
         load_panel(X2, n2, ldx2, idx2, t_lo * MF_T);
         load_v(t_lo * MF_T);
     }
     for (int64_t t = t_lo; t < t_hi; ++t) {
         if (((t - t_lo) & 15) == 15) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < KVN; ++c) {
+                    yvt[b][c] += yv[b][c];
+                    yv[b][c] = 0.f;
+                }
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 ytot[b] += yacc[b];
@@ -204,31 +221,61 @@ kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
                     acc[a][b][v] = mf_kappa<RBF>(kind, s, w, rbf_c);
                 }
             }
+            if constexpr (KV == 0) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                // A operand of step v: V[j = row v of this lane half][c = lane%32] (zero for c >= 16)
-                const float av = li < 16 ? VS[wm + a * 32 + mf_row(v, lk)][li] : 0.f;
+                for (int v = 0; v < 16; ++v) {
+                    // A operand of step v: V[j = row v of this lane half][c = lane%32] (zero for c >= 16)
+                    const float av = li < 16 ? VS[wm + a * 32 + mf_row(v, lk)][li] : 0.f;
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
-                    yacc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, acc[a][b][v], yacc[b], 0, 0, 0);
+                    for (int b = 0; b < 2; ++b)
+                        yacc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, acc[a][b][v], yacc[b], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float* vj = VS[wm + a * 32 + mf_row(v, lk)];  // same address in a half-wave: broadcast
+#pragma unroll
+                    for (int c = 0; c < KV; ++c) {
+                        const float vv = vj[c];
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) yv[b][c] += acc[a][b][v] * vv;
+                    }
+                }
             }
         }
     }
-    // ---- combine the two waves of each i-range, write ------------------------------------------
-    __syncthreads();  // every wave is done with the panels: reuse S2 as [4 waves][16 c][64 i]
+    // ---- combine the partial sums of each i (two j-half waves; for KV > 0 also two lane halves) ------
+    __syncthreads();  // every wave is done with the panels: reuse S2 as [8 slots][16 c][64 i]
     float* yl = &S2[0][0];
+    constexpr int NSLOT = KV == 0 ? 2 : 4;  // contributions per (i, c)
+    if constexpr (KV == 0) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int v = 0; v < 8; ++v) {  // rhs c = mf_row(v, lk) < 16 for v < 8
-            const int c = mf_row(v, lk);
-            yl[(wave * 16 + c) * 64 + b * 32 + li] = ytot[b][v] + yacc[b][v];
-        }
+            for (int v = 0; v < 8; ++v) {  // rhs c = mf_row(v, lk) < 16 for v < 8
+                const int c = mf_row(v, lk);
+                yl[(wave * 16 + c) * 64 + b * 32 + li] = ytot[b][v] + yacc[b][v];
+            }
+    } else {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < KV; ++c)
+                yl[((wave * 2 + lk) * 16 + c) * 64 + b * 32 + li] = yvt[b][c] + yv[b][c];
+    }
     __syncthreads();
     for (int e = tid; e < MF_T * k; e += 256) {
         const int il = e / k, c = e - il * k;  // il: row within the block
         const int wcol = il >> 6;              // waves wcol (j half 0) and wcol + 2 (j half 1)
-        const float sum = yl[(wcol * 16 + c) * 64 + (il & 63)] + yl[((wcol + 2) * 16 + c) * 64 + (il & 63)];
+        float sum;
+        if constexpr (KV == 0) {
+            sum = yl[(wcol * 16 + c) * 64 + (il & 63)] + yl[((wcol + 2) * 16 + c) * 64 + (il & 63)];
+        } else {
+            const float s0 = yl[((wcol * 2 + 0) * 16 + c) * 64 + (il & 63)] + yl[((wcol * 2 + 1) * 16 + c) * 64 + (il & 63)];
+            const float s1 = yl[(((wcol + 2) * 2 + 0) * 16 + c) * 64 + (il & 63)] + yl[(((wcol + 2) * 2 + 1) * 16 + c) * 64 + (il & 63)];
+            sum = s0 + s1;
+        }
+        (void)NSLOT;
         const int64_t i = i0 + il;
         if (i >= n1) continue;
         if (part != nullptr) {
@@ -267,9 +314,16 @@ int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, con
     dim3 grid((unsigned)ceil_div(n1, MF_T), (unsigned)S);
 #define RK_MF(RBFV, VLDV)                                                                          \
     do {                                                                                           \
+        if (k == 1) RK_MF_K(RBFV, VLDV, 1);                                                        \
+        else if (k == 2) RK_MF_K(RBFV, VLDV, 2);                                                   \
+        else if (k <= 4) RK_MF_K(RBFV, VLDV, 4);                                                   \
+        else RK_MF_K(RBFV, VLDV, 0);                                                               \
+    } while (0)
+#define RK_MF_K(RBFV, VLDV, KVV)                                                                   \
+    do {                                                                                           \
         static bool attr_set = false;                                                              \
         if (!attr_set) {                                                                           \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kmat_matmat_mfma_kernel<RBFV, VLDV>), \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kmat_matmat_mfma_kernel<RBFV, VLDV, KVV>), \
                                     hipFuncAttributeMaxDynamicSharedMemorySize,                    \
                                     (int)MF_SMEM_BYTES) != hipSuccess) {                           \
                 (void)hipGetLastError();                                                           \
@@ -278,7 +332,7 @@ int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, con
             }                                                                                      \
             attr_set = true;                                                                       \
         }                                                                                          \
-        hipLaunchKernelGGL((kmat_matmat_mfma_kernel<RBFV, VLDV>), grid, dim3(256), MF_SMEM_BYTES, st, \
+        hipLaunchKernelGGL((kmat_matmat_mfma_kernel<RBFV, VLDV, KVV>), grid, dim3(256), MF_SMEM_BYTES, st, \
                            kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d, w, scale, nxp, nyp, V, k, \
                            ldv, tiles_per_seg, part, Y, ldy, accumulate);                          \
     } while (0)
@@ -292,6 +346,7 @@ int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, con
         else RK_MF(false, 1);
     }
 #undef RK_MF
+#undef RK_MF_K
     return launch_status("rk_kernel_matmat(mfma)");
 }
 
