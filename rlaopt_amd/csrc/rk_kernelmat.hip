@@ -646,9 +646,11 @@ int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, con
 // float32, L2 kernels, scalar lengthscale, d <= 64: the matrix-core formulation (rk_kernelmfma.hip;
 // 1.4 - 1.8x the VALU kernels: 534 vs 330 Gpair/s at d = 64, 484 vs 281 at d = 50, k = 10).
 // RK_KMAT_MFMA=0 in the environment (read per call) selects the direct-difference kernels.
+#ifndef RK_KMAT_MFMA_DMIN
+#define RK_KMAT_MFMA_DMIN 1
+#endif
 static bool kmat_use_mfma(bool is_f32, int kind, const void* ell_vec, int64_t d, int64_t n1, int64_t n2) {
-    // (d < 8: the contraction is too short to pay for the tile's fixed costs - 849 vs 1249 Gpair/s at d = 3)
-    if (!(is_f32 && kind != RK_LAPLACE && ell_vec == nullptr && d >= 8 && d <= 64 && n2 >= 128 && n1 >= 1))
+    if (!(is_f32 && kind != RK_LAPLACE && ell_vec == nullptr && d >= RK_KMAT_MFMA_DMIN && d <= 64 && n2 >= 128 && n1 >= 1))
         return false;
     const char* e = getenv("RK_KMAT_MFMA");
     return !(e != nullptr && e[0] == '0');
