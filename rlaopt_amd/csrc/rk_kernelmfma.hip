@@ -30,7 +30,7 @@ namespace rk {
 constexpr int MF_T = 128;    // tile edge (points)
 constexpr int MF_D = 64;     // features staged (d <= MF_D)
 constexpr int MF_LD = 130;   // LDS stride of the k-major panels (conflict-free transposing store)
-constexpr int MF_LDV = 17;   // stride of the V tile rows (16 rhs, contiguous)
+constexpr int MF_LDV = 20;   // stride of the V tile rows (16 rhs, contiguous; 16-byte aligned rows)
 
 typedef float mf_acc __attribute__((ext_vector_type(16)));
 
@@ -58,7 +58,8 @@ __device__ __forceinline__ float mf_kappa(int kind, float s, float w, float rbf_
 
 // KV = 0: the second product on the matrix cores (rhs padded to 32).  KV = 1 / 2 / 4 (k <= KV):
 // the second product on the VALU - per lane 64 * KV FMAs per tile into 2 * KV running sums, a
-// sixteenth of the MFMA work the padded form would spend on so few right-hand sides.
+// sixteenth of the MFMA work the padded form would spend on so few right-hand sides.  (KV = 8 / 16
+// were tried: the 2 * KV running sums spill, 6 - 14 % slower than the matrix cores at k = 10 / 16.)
 template <bool RBF, int VLD, int KV>
 __global__ void __launch_bounds__(256, 2)
 kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int64_t ldx1,
@@ -234,12 +235,21 @@ kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const float* vj = VS[wm + a * 32 + mf_row(v, lk)];  // same address in a half-wave: broadcast
+                    float vv[KV];
+                    if constexpr (KV >= 4) {
 #pragma unroll
-                    for (int c = 0; c < KV; ++c) {
-                        const float vv = vj[c];
+                        for (int c = 0; c < KV; c += 4) {
+                            const float4 q = *reinterpret_cast<const float4*>(vj + c);
+                            vv[c] = q.x; vv[c + 1] = q.y; vv[c + 2] = q.z; vv[c + 3] = q.w;
+                        }
+                    } else {
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) yv[b][c] += acc[a][b][v] * vv;
+                        for (int c = 0; c < KV; ++c) vv[c] = vj[c];
                     }
+#pragma unroll
+                    for (int c = 0; c < KV; ++c)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) yv[b][c] += acc[a][b][v] * vv[c];
                 }
             }
         }
