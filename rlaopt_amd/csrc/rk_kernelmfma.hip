@@ -34,16 +34,23 @@ constexpr int MF_LDV = 20;   // stride of the V tile rows (16 rhs, contiguous; 1
 
 typedef float mf_acc __attribute__((ext_vector_type(16)));
 
-// |row|^2 of gathered rows: out[p] = sum_c X[row(p)][c]^2
+// |row|^2 of gathered rows: out[p] = sum_c X[row(p)][c]^2.  16 lanes (one DPP row) per point, the
+// features strided over them: a wave reads 4 rows in 64-byte runs instead of 64 rows 4 bytes each
 __global__ void __launch_bounds__(256)
 row_norms_kernel(const float* __restrict__ X, int64_t ldx, const int64_t* __restrict__ idx, int64_t n,
                  int64_t d, float* __restrict__ out) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const float* row = X + (idx ? idx[p] : p) * ldx;
+    const int64_t p = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int l = threadIdx.x & 15;
     float s = 0.f;
-    for (int64_t c = 0; c < d; ++c) s += row[c] * row[c];
-    out[p] = s;
+    if (p < n) {
+        const float* row = X + (idx ? idx[p] : p) * ldx;
+        for (int64_t c = l; c < d; c += 16) s += row[c] * row[c];
+    }
+    s += dpp_fetch<0xB1, 0xF>(s);   // quad_perm [1,0,3,2]
+    s += dpp_fetch<0x4E, 0xF>(s);   // quad_perm [2,3,0,1]
+    s += dpp_fetch<0x141, 0xF>(s);  // row_half_mirror
+    s += dpp_fetch<0x140, 0xF>(s);  // row_mirror: every lane of the row holds the sum
+    if (p < n && l == 0) out[p] = s;
 }
 
 // element v of a 32x32 accumulator sits in row (v&3) + 8*(v>>2) + 4*(lane/32), column lane%32
@@ -309,9 +316,9 @@ int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, con
                         int accumulate, hipStream_t st) {
     float* nxp = norms;
     float* nyp = norms + n1;
-    hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)ceil_div(n1, 256)), dim3(256), 0, st, X1, ldx1,
+    hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)ceil_div(n1, 16)), dim3(256), 0, st, X1, ldx1,
                        idx1, n1, d, nxp);
-    hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)ceil_div(n2, 256)), dim3(256), 0, st, X2, ldx2,
+    hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)ceil_div(n2, 16)), dim3(256), 0, st, X2, ldx2,
                        idx2, n2, d, nyp);
     auto align = [&](const float* X, int64_t ldx) {  // widest vector load of a row piece
         const uintptr_t a = reinterpret_cast<uintptr_t>(X);
