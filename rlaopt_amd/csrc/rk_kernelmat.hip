@@ -639,18 +639,20 @@ static void launch_kmatmat_wide(int KB, dim3 grid, hipStream_t st, int kind, con
 // rk_kernelmfma.hip: the attention-shaped formulation on the matrix cores (fp32, L2 kernels)
 int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
                         const float* X2, int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d,
-                        float w, float scale, const float* V, int k, int64_t ldv, int64_t S,
+                        float w, const float* ell_vec, float scale, const float* V, int k, int64_t ldv,
+                        int64_t S,
                         int64_t tiles_per_seg, float* norms, float* part, float* Y, int64_t ldy,
                         int accumulate, hipStream_t st);
 
-// float32, L2 kernels, scalar lengthscale, d <= 64: the matrix-core formulation (rk_kernelmfma.hip;
+// float32, L2 kernels, d <= 64: the matrix-core formulation (rk_kernelmfma.hip;
 // 1.4 - 1.8x the VALU kernels: 534 vs 330 Gpair/s at d = 64, 484 vs 281 at d = 50, k = 10).
 // RK_KMAT_MFMA=0 in the environment (read per call) selects the direct-difference kernels.
 #ifndef RK_KMAT_MFMA_DMIN
 #define RK_KMAT_MFMA_DMIN 1
 #endif
 static bool kmat_use_mfma(bool is_f32, int kind, const void* ell_vec, int64_t d, int64_t n1, int64_t n2) {
-    if (!(is_f32 && kind != RK_LAPLACE && ell_vec == nullptr && d >= RK_KMAT_MFMA_DMIN && d <= 64 && n2 >= 128 && n1 >= 1))
+    (void)ell_vec;  // scalar and per-feature lengthscales both
+    if (!(is_f32 && kind != RK_LAPLACE && d >= RK_KMAT_MFMA_DMIN && d <= 64 && n2 >= 128 && n1 >= 1))
         return false;
     const char* e = getenv("RK_KMAT_MFMA");
     return !(e != nullptr && e[0] == '0');
@@ -691,7 +693,7 @@ static int kmatmat_impl(int kind, const T* X1, int64_t n1, int64_t ldx1, const i
             float* partm = pm.S > 1 ? static_cast<float*>(ws) : nullptr;
             float* norms = reinterpret_cast<float*>(static_cast<char*>(ws) + off);
             int rcm = launch_kmatmat_mfma(kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d, (float)w,
-                                          (float)scale, V, (int)k, ldv, pm.S, pm.tiles_per_seg, norms,
+                                          ell_vec, (float)scale, V, (int)k, ldv, pm.S, pm.tiles_per_seg, norms,
                                           partm, Y, ldy, accumulate, st);
             if (rcm != RK_OK || partm == nullptr) return rcm;
             hipLaunchKernelGGL((kmat_matmat_finish<T>), dim3((unsigned)ceil_div(n1 * k, 256)), dim3(256),

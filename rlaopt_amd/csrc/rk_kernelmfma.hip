@@ -38,13 +38,16 @@ typedef float mf_acc __attribute__((ext_vector_type(16)));
 // features strided over them: a wave reads 4 rows in 64-byte runs instead of 64 rows 4 bytes each
 __global__ void __launch_bounds__(256)
 row_norms_kernel(const float* __restrict__ X, int64_t ldx, const int64_t* __restrict__ idx, int64_t n,
-                 int64_t d, float* __restrict__ out) {
+                 int64_t d, const float* __restrict__ ell_vec, float* __restrict__ out) {
     const int64_t p = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int l = threadIdx.x & 15;
     float s = 0.f;
     if (p < n) {
         const float* row = X + (idx ? idx[p] : p) * ldx;
-        for (int64_t c = l; c < d; c += 16) s += row[c] * row[c];
+        for (int64_t c = l; c < d; c += 16) {
+            const float x = ell_vec ? row[c] / ell_vec[c] : row[c];
+            s += x * x;
+        }
     }
     s += dpp_fetch<0xB1, 0xF>(s);   // quad_perm [1,0,3,2]
     s += dpp_fetch<0x4E, 0xF>(s);   // quad_perm [2,3,0,1]
@@ -72,7 +75,8 @@ __global__ void __launch_bounds__(256, 2)
 kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int64_t ldx1,
                         const int64_t* __restrict__ idx1, const float* __restrict__ X2, int64_t n2,
                         int64_t ldx2, const int64_t* __restrict__ idx2, int64_t d, float w,
-                        float scale, const float* __restrict__ nx, const float* __restrict__ ny,
+                        const float* __restrict__ ell_vec, float scale, const float* __restrict__ nx,
+                        const float* __restrict__ ny,
                         const float* __restrict__ V, int k, int64_t ldv, int64_t tiles_per_seg,
                         float* __restrict__ part, float* __restrict__ Y, int64_t ldy, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -118,6 +122,11 @@ kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
                     for (int e = 0; e < VLD; ++e) xr[u + e] = 0.f;
                 }
             }
+        }
+        if (ell_vec != nullptr) {  // per-feature lengthscales (ARD): features are divided on the way in
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+                if (sf + u < d) xr[u] = xr[u] / ell_vec[sf + u];
         }
     };
     auto store_panel = [&](float (*dst)[MF_LD]) {
@@ -311,15 +320,16 @@ constexpr size_t MF_SMEM_BYTES =
 // launch (float32 only): norms of both point sets into `norms` (n1 + n2 floats), then the tiles
 int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
                         const float* X2, int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d,
-                        float w, float scale, const float* V, int k, int64_t ldv, int64_t S,
+                        float w, const float* ell_vec, float scale, const float* V, int k, int64_t ldv,
+                        int64_t S,
                         int64_t tiles_per_seg, float* norms, float* part, float* Y, int64_t ldy,
                         int accumulate, hipStream_t st) {
     float* nxp = norms;
     float* nyp = norms + n1;
     hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)ceil_div(n1, 16)), dim3(256), 0, st, X1, ldx1,
-                       idx1, n1, d, nxp);
+                       idx1, n1, d, ell_vec, nxp);
     hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)ceil_div(n2, 16)), dim3(256), 0, st, X2, ldx2,
-                       idx2, n2, d, nyp);
+                       idx2, n2, d, ell_vec, nyp);
     auto align = [&](const float* X, int64_t ldx) {  // widest vector load of a row piece
         const uintptr_t a = reinterpret_cast<uintptr_t>(X);
         if (a % 16 == 0 && ldx % 4 == 0 && d % 4 == 0) return 4;
@@ -350,8 +360,8 @@ int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, con
             attr_set = true;                                                                       \
         }                                                                                          \
         hipLaunchKernelGGL((kmat_matmat_mfma_kernel<RBFV, VLDV, KVV>), grid, dim3(256), MF_SMEM_BYTES, st, \
-                           kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d, w, scale, nxp, nyp, V, k, \
-                           ldv, tiles_per_seg, part, Y, ldy, accumulate);                          \
+                           kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d, w, ell_vec, scale, nxp, nyp, V, \
+                           k, ldv, tiles_per_seg, part, Y, ldy, accumulate);                       \
     } while (0)
     if (kind == RK_RBF) {
         if (vld == 4) RK_MF(true, 4);
