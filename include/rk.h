@@ -81,7 +81,31 @@ int rk_kernel_matmat(int dtype, int kind,
                      int64_t d, double ell_scalar, const void* ell_vec, double scale,
                      const void* V, int64_t k, int64_t ldv,
                      void* Y, int64_t ldy, int accumulate,
-                     void* ws, size_t ws_bytes, void* stream);
+                     const void* gram_center, void* ws, size_t ws_bytes, void* stream);
+
+/* `gram_center` (device, length d, same dtype; may be NULL) opts in to the matrix-core
+ * formulation of the float32 product (RBF, Matern-3/2, Matern-5/2, d <= 64), which expands
+ * |x - y|^2 = |x'|^2 + |y'|^2 - 2 x'.y' with x' = (x - gram_center) / ell.  Its rounding error
+ * grows with |x'|^2, so by passing a centre the caller vouches that
+ *     max_i |(x_i - gram_center) / ell|^2 <= RK_GRAM_MAX_NORM2
+ * over the rows of X1 and X2 (rk_kernel_gram_bound computes that maximum).  Entries then agree
+ * with the direct (x - y)^2 evaluation to ~1e-5 absolute, the diagonal of K(X, X) included
+ * (reference tolerance for float32: 1e-4, tests/kernels/test_standard.py).  NULL, float64,
+ * Laplace, Matern-1/2 (not smooth in the squared distance) and d > 64 always take the direct-
+ * difference kernels.  pykeops (the reference's engine) evaluates the direct form. */
+#define RK_GRAM_MAX_NORM2 32.0
+
+/* center[c] = mean of column c over <= 4096 evenly strided rows of X (n x d): a deterministic,
+ * cheap origin for the expansion above (the kernels are translation invariant, any point near
+ * the data will do). */
+int rk_kernel_center(int dtype, const void* X, int64_t n, int64_t ldx, int64_t d,
+                     void* center, void* stream);
+/* bound[0] = max(bound[0], max_i sum_c ((X[i][c] - center[c]) / ell_c)^2); `bound` is ONE
+ * device element of `dtype` that the caller zero-initialises (and may carry over several point
+ * sets).  Rows containing NaN give +inf. */
+int rk_kernel_gram_bound(int dtype, const void* X, int64_t n, int64_t ldx, int64_t d,
+                         double ell_scalar, const void* ell_vec, const void* center,
+                         void* bound, void* stream);
 
 /* Symmetric operators K(X, X), "sympack" storage: columns are cut into strips of
  * W = 256 (f32) / 128 (f64) columns; strip s keeps rows 0 .. min(n, (s+1) W) - 1 of its W

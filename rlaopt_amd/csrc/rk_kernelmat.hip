@@ -639,20 +639,22 @@ static void launch_kmatmat_wide(int KB, dim3 grid, hipStream_t st, int kind, con
 // rk_kernelmfma.hip: the attention-shaped formulation on the matrix cores (fp32, L2 kernels)
 int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
                         const float* X2, int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d,
-                        float w, const float* ell_vec, float scale, const float* V, int k, int64_t ldv,
-                        int64_t S,
+                        float w, const float* ell_vec, const float* center, float scale, const float* V,
+                        int k, int64_t ldv, int64_t S,
                         int64_t tiles_per_seg, float* norms, float* part, float* Y, int64_t ldy,
                         int accumulate, hipStream_t st);
 
-// float32, L2 kernels, d <= 64: the matrix-core formulation (rk_kernelmfma.hip;
-// 1.4 - 1.8x the VALU kernels: 534 vs 330 Gpair/s at d = 64, 484 vs 281 at d = 50, k = 10).
+// float32, kernels smooth in the squared distance (RBF, Matern-3/2, -5/2), d <= 64, and a
+// `gram_center` from the caller (who thereby vouches for the norm bound, see rk.h): the matrix-core
+// formulation (rk_kernelmfma.hip; 1.4 - 2.2x the VALU kernels: 711 vs 330 Gpair/s at d = 64,
+// 470 vs 281 at d = 50, k = 10).  Scalar and per-feature lengthscales both.
 // RK_KMAT_MFMA=0 in the environment (read per call) selects the direct-difference kernels.
 #ifndef RK_KMAT_MFMA_DMIN
 #define RK_KMAT_MFMA_DMIN 1
 #endif
-static bool kmat_use_mfma(bool is_f32, int kind, const void* ell_vec, int64_t d, int64_t n1, int64_t n2) {
-    (void)ell_vec;  // scalar and per-feature lengthscales both
-    if (!(is_f32 && kind != RK_LAPLACE && d >= RK_KMAT_MFMA_DMIN && d <= 64 && n2 >= 128 && n1 >= 1))
+static bool kmat_use_mfma(bool is_f32, int kind, const void* center, int64_t d, int64_t n1, int64_t n2) {
+    if (!(is_f32 && center != nullptr && kind != RK_LAPLACE && kind != RK_MATERN12 &&
+          d >= RK_KMAT_MFMA_DMIN && d <= 64 && n2 >= 128 && n1 >= 1))
         return false;
     const char* e = getenv("RK_KMAT_MFMA");
     return !(e != nullptr && e[0] == '0');
@@ -673,19 +675,22 @@ static KMPlan plan_kmatmat_mfma(int64_t n1, int64_t n2) {
 static size_t kmat_norms_offset(int64_t S, int64_t n1, int64_t k) {  // norms sit behind the partials
     return round_up((size_t)(S > 1 ? S : 0) * n1 * k * sizeof(float), 256);
 }
+static size_t kmat_norms_bytes(int64_t n1, int64_t n2) {  // affine map (2 x 64) + |x'|^2 of both sets
+    return (size_t)(2 * 64 + n1 + n2) * sizeof(float);
+}
 
 template <typename T>
 static int kmatmat_impl(int kind, const T* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
                         const T* X2, int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d,
                         double ell, const T* ell_vec, double scale, const T* V, int64_t k,
-                        int64_t ldv, T* Y, int64_t ldy, int accumulate, void* ws, size_t ws_bytes,
-                        hipStream_t st) {
+                        int64_t ldv, T* Y, int64_t ldy, int accumulate, const T* gram_center, void* ws,
+                        size_t ws_bytes, hipStream_t st) {
     const T w = ell_vec ? T(1) : T(1.0 / ell);
     if constexpr (sizeof(T) == 4) {
-        if (kmat_use_mfma(true, kind, ell_vec, d, n1, n2)) {
+        if (kmat_use_mfma(true, kind, gram_center, d, n1, n2)) {
             const KMPlan pm = plan_kmatmat_mfma(n1, n2);
             const size_t off = kmat_norms_offset(pm.S, n1, k);
-            const size_t need = off + (size_t)(n1 + n2) * sizeof(float);
+            const size_t need = off + kmat_norms_bytes(n1, n2);
             if (ws == nullptr || ws_bytes < need) {
                 set_error("rk_kernel_matmat: workspace %zu B < required %zu B", ws_bytes, need);
                 return RK_ERR_WORKSPACE;
@@ -693,7 +698,8 @@ static int kmatmat_impl(int kind, const T* X1, int64_t n1, int64_t ldx1, const i
             float* partm = pm.S > 1 ? static_cast<float*>(ws) : nullptr;
             float* norms = reinterpret_cast<float*>(static_cast<char*>(ws) + off);
             int rcm = launch_kmatmat_mfma(kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d, (float)w,
-                                          ell_vec, (float)scale, V, (int)k, ldv, pm.S, pm.tiles_per_seg, norms,
+                                          ell_vec, gram_center, (float)scale, V, (int)k, ldv, pm.S,
+                                          pm.tiles_per_seg, norms,
                                           partm, Y, ldy, accumulate, st);
             if (rcm != RK_OK || partm == nullptr) return rcm;
             hipLaunchKernelGGL((kmat_matmat_finish<T>), dim3((unsigned)ceil_div(n1 * k, 256)), dim3(256),
@@ -792,7 +798,7 @@ extern "C" size_t rk_kernel_matmat_ws_bytes(int dtype, int64_t n1, int64_t n2, i
     size_t bytes = S > 1 ? (size_t)S * n1 * k * (dtype == RK_F32 ? 4 : 8) : 0;
     if (dtype == RK_F32) {  // the matrix-core path: its partials + the |x|^2 of both point sets
         const KMPlan pm = plan_kmatmat_mfma(n1, n2);
-        const size_t m = kmat_norms_offset(pm.S, n1, k) + (size_t)(n1 + n2) * sizeof(float);
+        const size_t m = kmat_norms_offset(pm.S, n1, k) + kmat_norms_bytes(n1, n2);
         if (m > bytes) bytes = m;
     }
     return bytes;
@@ -802,8 +808,8 @@ extern "C" int rk_kernel_matmat(int dtype, int kind, const void* X1, int64_t n1,
                                 const int64_t* idx1, const void* X2, int64_t n2, int64_t ldx2,
                                 const int64_t* idx2, int64_t d, double ell_scalar,
                                 const void* ell_vec, double scale, const void* V, int64_t k,
-                                int64_t ldv, void* Y, int64_t ldy, int accumulate, void* ws,
-                                size_t ws_bytes, void* stream) {
+                                int64_t ldv, void* Y, int64_t ldy, int accumulate,
+                                const void* gram_center, void* ws, size_t ws_bytes, void* stream) {
     clear_error();
     int rc = check_kernel_args("rk_kernel_matmat", dtype, kind, X1, n1, ldx1, X2, n2, ldx2, d,
                                ell_scalar, ell_vec);
@@ -815,9 +821,10 @@ extern "C" int rk_kernel_matmat(int dtype, int kind, const void* X1, int64_t n1,
     if (dtype == RK_F32)
         return kmatmat_impl<float>(kind, (const float*)X1, n1, ldx1, idx1, (const float*)X2, n2,
                                    ldx2, idx2, d, ell_scalar, (const float*)ell_vec, scale,
-                                   (const float*)V, k, ldv, (float*)Y, ldy, accumulate, ws, ws_bytes,
-                                   st);
+                                   (const float*)V, k, ldv, (float*)Y, ldy, accumulate,
+                                   (const float*)gram_center, ws, ws_bytes, st);
     return kmatmat_impl<double>(kind, (const double*)X1, n1, ldx1, idx1, (const double*)X2, n2, ldx2,
                                 idx2, d, ell_scalar, (const double*)ell_vec, scale, (const double*)V,
-                                k, ldv, (double*)Y, ldy, accumulate, ws, ws_bytes, st);
+                                k, ldv, (double*)Y, ldy, accumulate, (const double*)gram_center, ws,
+                                ws_bytes, st);
 }

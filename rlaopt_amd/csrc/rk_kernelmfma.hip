@@ -12,8 +12,16 @@
 // The VALU-formulated kernels (rk_kernelmat.hip) are bound by 2 vector instructions per pair and
 // feature; here the d-long contraction runs on the MFMA pipe (64 flop/clk/SIMD, twice the scalar
 // FMA rate, and 2 instead of 3 flops per pair and feature) and the VALU only evaluates kappa.
-// |x|^2 + |y|^2 - 2 x.y cancels to ~1e-7 absolute in fp32 - inside the fp32 tolerance (1e-4);
-// float64 keeps the direct (x - y)^2 kernels for its 1e-8 tolerance, and so does Laplace (L1).
+// Accuracy.  s = |x|^2 + |y|^2 - 2 x.y is formed from three rounded float32 sums, so its absolute
+// error is ~ eps32 * (|x|^2 + |y|^2) / ell^2 whatever the true distance is.  The kernels are
+// translation invariant, so both panels are CENTRED on the way into LDS (x' = (x - c) / ell, c
+// given by the caller: rk_kernel_center) and the caller vouches for max |x'|^2 <= RK_GRAM_MAX_NORM2
+// (rk_kernel_gram_bound): the error of s is then <= ~1e-5 and the entry-wise error of a kernel
+// that is smooth in s (RBF, Matern-3/2, -5/2: |d kappa / d s| <= 3/2) stays an order of magnitude
+// inside the float32 tolerance of the reference tests (1e-4) - including the diagonal of
+// K(X, X), where s should be 0 and is ~1e-6 instead.  Matern-1/2 = exp(-sqrt(s)) is NOT smooth
+// at s = 0 (sqrt(1e-6) = 1e-3): it keeps the direct (x - y)^2 kernels, like Laplace (L1) and
+// float64 (1e-8 tolerance).  Without a centre from the caller the direct kernels run.
 //
 // Workgroup = 4 waves (2 x 2), tile = 128 points of X2 (j) x 128 points of X1 (i); a wave owns
 // 64 j x 64 i = 2 x 2 MFMA blocks.  The X1 block stays in LDS (k-major) for the whole kernel; the
@@ -22,6 +30,8 @@
 // workgroups per CU, so one workgroup's MFMAs overlap the other's kappa evaluation and waits.
 // Per wave Y^T lives in 2 accumulators (32 rhs x 32 i each) for all tiles; at the end the two
 // waves that share an i-range add theirs through LDS (fixed order).
+#include <atomic>
+
 #include "rk_common.h"
 #include "rk_kerneltile.h"
 
@@ -34,18 +44,34 @@ constexpr int MF_LDV = 20;   // stride of the V tile rows (16 rhs, contiguous; 1
 
 typedef float mf_acc __attribute__((ext_vector_type(16)));
 
-// |row|^2 of gathered rows: out[p] = sum_c X[row(p)][c]^2.  16 lanes (one DPP row) per point, the
-// features strided over them: a wave reads 4 rows in 64-byte runs instead of 64 rows 4 bytes each
+// per-feature affine map of the staged panels: x' = x * iw[c] - muw[c] with iw = 1/ell_c (1 for a
+// scalar lengthscale, which kappa applies) and muw = centre_c * iw[c]; entries c >= d are zero
+__global__ void gram_prep_kernel(const float* __restrict__ center, const float* __restrict__ ell_vec,
+                                 int64_t d, float* __restrict__ iw, float* __restrict__ muw) {
+    const int c = threadIdx.x;  // MF_D threads
+    float a = 0.f, b = 0.f;
+    if (c < d) {
+        a = ell_vec ? 1.f / ell_vec[c] : 1.f;
+        b = center[c] * a;
+    }
+    iw[c] = a;
+    muw[c] = b;
+}
+
+// |row'|^2 of gathered, centred, scaled rows: out[p] = sum_c (X[row(p)][c] iw[c] - muw[c])^2.
+// 16 lanes (one DPP row) per point, the features strided over them: a wave reads 4 rows in
+// 64-byte runs instead of 64 rows 4 bytes each
 __global__ void __launch_bounds__(256)
 row_norms_kernel(const float* __restrict__ X, int64_t ldx, const int64_t* __restrict__ idx, int64_t n,
-                 int64_t d, const float* __restrict__ ell_vec, float* __restrict__ out) {
+                 int64_t d, const float* __restrict__ iw, const float* __restrict__ muw,
+                 float* __restrict__ out) {
     const int64_t p = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int l = threadIdx.x & 15;
     float s = 0.f;
     if (p < n) {
         const float* row = X + (idx ? idx[p] : p) * ldx;
         for (int64_t c = l; c < d; c += 16) {
-            const float x = ell_vec ? row[c] / ell_vec[c] : row[c];
+            const float x = fmaf(row[c], iw[c], -muw[c]);
             s += x * x;
         }
     }
@@ -75,8 +101,8 @@ __global__ void __launch_bounds__(256, 2)
 kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int64_t ldx1,
                         const int64_t* __restrict__ idx1, const float* __restrict__ X2, int64_t n2,
                         int64_t ldx2, const int64_t* __restrict__ idx2, int64_t d, float w,
-                        const float* __restrict__ ell_vec, float scale, const float* __restrict__ nx,
-                        const float* __restrict__ ny,
+                        const float* __restrict__ iw, const float* __restrict__ muw, float scale,
+                        const float* __restrict__ nx, const float* __restrict__ ny,
                         const float* __restrict__ V, int k, int64_t ldv, int64_t tiles_per_seg,
                         float* __restrict__ part, float* __restrict__ Y, int64_t ldy, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -84,6 +110,8 @@ kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
     float (*S2)[MF_LD] = reinterpret_cast<float (*)[MF_LD]>(smem + MF_D * MF_LD);     // [MF_D][MF_LD]
     float (*VS)[MF_LDV] = reinterpret_cast<float (*)[MF_LDV]>(smem + 2 * MF_D * MF_LD);  // [MF_T][MF_LDV]
     float* NY = smem + 2 * MF_D * MF_LD + MF_T * MF_LDV;                              // [MF_T]
+    float* IW = NY + MF_T;                                                            // [MF_D]
+    float* MUW = IW + MF_D;                                                           // [MF_D]
     const float rbf_c = -0.5f * w * w * 1.4426950408889634f;
 
     const int tid = threadIdx.x;
@@ -123,10 +151,19 @@ kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
                 }
             }
         }
-        if (ell_vec != nullptr) {  // per-feature lengthscales (ARD): features are divided on the way in
+        // centre and scale on the way in (staged once per workgroup in LDS; the two feature
+        // halves read two addresses per wave: broadcasts).  Padded points stay zero: their V rows
+        // are zero, and padded features have iw = muw = 0.
+        if (row != nullptr) {
 #pragma unroll
-            for (int u = 0; u < 32; ++u)
-                if (sf + u < d) xr[u] = xr[u] / ell_vec[sf + u];
+            for (int u = 0; u < 32; u += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(IW + sf + u);
+                const float4 b = *reinterpret_cast<const float4*>(MUW + sf + u);
+                xr[u] = fmaf(xr[u], a.x, -b.x);
+                xr[u + 1] = fmaf(xr[u + 1], a.y, -b.y);
+                xr[u + 2] = fmaf(xr[u + 2], a.z, -b.z);
+                xr[u + 3] = fmaf(xr[u + 3], a.w, -b.w);
+            }
         }
     };
     auto store_panel = [&](float (*dst)[MF_LD]) {
@@ -149,6 +186,11 @@ kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
         if (tid < MF_T) NY[tid] = nyr;
     };
 
+    if (tid < MF_D) {
+        IW[tid] = iw[tid];
+        MUW[tid] = muw[tid];
+    }
+    __syncthreads();
     // X1 block: resident for the whole kernel
     load_panel(X1, n1, ldx1, idx1, i0);
     store_panel(S1);
@@ -315,21 +357,25 @@ kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
 }
 
 constexpr size_t MF_SMEM_BYTES =
-    sizeof(float) * (2 * MF_D * MF_LD + MF_T * MF_LDV + MF_T);  // S1 + S2 + VS + NY
+    sizeof(float) * (2 * MF_D * MF_LD + MF_T * MF_LDV + MF_T + 2 * MF_D);  // S1 + S2 + VS + NY + IW + MUW
 
-// launch (float32 only): norms of both point sets into `norms` (n1 + n2 floats), then the tiles
+// launch (float32 only): the affine map (2 * MF_D floats) and the norms of both point sets go into
+// `norms` (2 * MF_D + n1 + n2 floats), then the tiles
 int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
                         const float* X2, int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d,
-                        float w, const float* ell_vec, float scale, const float* V, int k, int64_t ldv,
-                        int64_t S,
+                        float w, const float* ell_vec, const float* center, float scale, const float* V,
+                        int k, int64_t ldv, int64_t S,
                         int64_t tiles_per_seg, float* norms, float* part, float* Y, int64_t ldy,
                         int accumulate, hipStream_t st) {
-    float* nxp = norms;
-    float* nyp = norms + n1;
+    float* iw = norms;
+    float* muw = norms + MF_D;
+    float* nxp = norms + 2 * MF_D;
+    float* nyp = nxp + n1;
+    hipLaunchKernelGGL(gram_prep_kernel, dim3(1), dim3(MF_D), 0, st, center, ell_vec, d, iw, muw);
     hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)ceil_div(n1, 16)), dim3(256), 0, st, X1, ldx1,
-                       idx1, n1, d, ell_vec, nxp);
+                       idx1, n1, d, iw, muw, nxp);
     hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)ceil_div(n2, 16)), dim3(256), 0, st, X2, ldx2,
-                       idx2, n2, d, ell_vec, nyp);
+                       idx2, n2, d, iw, muw, nyp);
     auto align = [&](const float* X, int64_t ldx) {  // widest vector load of a row piece
         const uintptr_t a = reinterpret_cast<uintptr_t>(X);
         if (a % 16 == 0 && ldx % 4 == 0 && d % 4 == 0) return 4;
@@ -348,8 +394,11 @@ int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, con
     } while (0)
 #define RK_MF_K(RBFV, VLDV, KVV)                                                                   \
     do {                                                                                           \
-        static bool attr_set = false;                                                              \
-        if (!attr_set) {                                                                           \
+        static std::atomic<unsigned long long> attr_devs{0}; /* one bit per device ordinal */        \
+        int dev_ = 0;                                                                              \
+        (void)hipGetDevice(&dev_);                                                                 \
+        const unsigned long long bit_ = 1ull << (dev_ & 63);                                       \
+        if (!(attr_devs.load(std::memory_order_acquire) & bit_)) {                                 \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kmat_matmat_mfma_kernel<RBFV, VLDV, KVV>), \
                                     hipFuncAttributeMaxDynamicSharedMemorySize,                    \
                                     (int)MF_SMEM_BYTES) != hipSuccess) {                           \
@@ -357,10 +406,10 @@ int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, con
                 set_error("rk_kernel_matmat: cannot reserve %zu bytes of LDS", MF_SMEM_BYTES);     \
                 return RK_ERR_LAUNCH;                                                              \
             }                                                                                      \
-            attr_set = true;                                                                       \
+            attr_devs.fetch_or(bit_, std::memory_order_release);                                   \
         }                                                                                          \
         hipLaunchKernelGGL((kmat_matmat_mfma_kernel<RBFV, VLDV, KVV>), grid, dim3(256), MF_SMEM_BYTES, st, \
-                           kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d, w, ell_vec, scale, nxp, nyp, V, \
+                           kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d, w, iw, muw, scale, nxp, nyp, V, \
                            k, ldv, tiles_per_seg, part, Y, ldy, accumulate);                       \
     } while (0)
     if (kind == RK_RBF) {
@@ -377,4 +426,89 @@ int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, con
     return launch_status("rk_kernel_matmat(mfma)");
 }
 
+// ---- centre and norm bound of a point set (the caller-side guard of the formulation above) ------
+
+// centre[c] = mean over <= 4096 evenly strided rows (any point near the data works as the origin;
+// a fixed sample keeps this a one-workgroup, fixed-order - bitwise reproducible - reduction)
+template <typename T>
+__global__ void __launch_bounds__(256)
+center_sample_kernel(const T* __restrict__ X, int64_t n, int64_t ldx, int64_t d, T* __restrict__ center) {
+    __shared__ double red[4][64];
+    const int g = threadIdx.x >> 6, cl = threadIdx.x & 63;
+    const int64_t stride = n > 4096 ? n / 4096 : 1;
+    const int64_t ns = (n + stride - 1) / stride;
+    for (int64_t c0 = 0; c0 < d; c0 += 64) {
+        const int64_t c = c0 + cl;
+        double s = 0.0;
+        if (c < d)
+            for (int64_t r = g; r < ns; r += 4) s += (double)X[r * stride * ldx + c];
+        red[g][cl] = s;
+        __syncthreads();
+        if (g == 0 && c < d) center[c] = (T)((red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / (double)ns);
+        __syncthreads();
+    }
+}
+
+// out[0] = max(out[0], max_p sum_c ((X[p][c] - centre[c]) / ell_c)^2): the maximum of non-negative
+// floats is the maximum of their bit patterns, and a maximum does not depend on the order
+template <typename T>
+__global__ void __launch_bounds__(256)
+gram_bound_kernel(const T* __restrict__ X, int64_t n, int64_t ldx, int64_t d, T w,
+                  const T* __restrict__ ell_vec, const T* __restrict__ center, T* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int l = threadIdx.x & 15;
+    T s = T(0);
+    if (p < n) {
+        const T* row = X + p * ldx;
+        for (int64_t c = l; c < d; c += 16) {
+            const T x = (row[c] - center[c]) * (ell_vec ? T(1) / ell_vec[c] : w);
+            s += x * x;
+        }
+    }
+    s += dpp_fetch<0xB1, 0xF>(s);
+    s += dpp_fetch<0x4E, 0xF>(s);
+    s += dpp_fetch<0x141, 0xF>(s);
+    s += dpp_fetch<0x140, 0xF>(s);
+    if (p < n && l == 0) {
+        if (!(s == s)) s = T(INFINITY);  // NaN data: never vouch for it
+        if constexpr (sizeof(T) == 4) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(s));
+        else atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(s));
+    }
+}
+
 }  // namespace rk
+
+using namespace rk;
+
+extern "C" int rk_kernel_center(int dtype, const void* X, int64_t n, int64_t ldx, int64_t d,
+                                void* center, void* stream) {
+    clear_error();
+    RK_REQUIRE(dtype == RK_F32 || dtype == RK_F64, "rk_kernel_center: bad dtype %d", dtype);
+    RK_REQUIRE(X && center && n > 0 && d > 0 && ldx >= d, "rk_kernel_center: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == RK_F32)
+        hipLaunchKernelGGL(center_sample_kernel<float>, dim3(1), dim3(256), 0, st, (const float*)X, n, ldx, d,
+                           (float*)center);
+    else
+        hipLaunchKernelGGL(center_sample_kernel<double>, dim3(1), dim3(256), 0, st, (const double*)X, n, ldx,
+                           d, (double*)center);
+    return launch_status("rk_kernel_center");
+}
+
+extern "C" int rk_kernel_gram_bound(int dtype, const void* X, int64_t n, int64_t ldx, int64_t d,
+                                    double ell_scalar, const void* ell_vec, const void* center,
+                                    void* bound, void* stream) {
+    clear_error();
+    RK_REQUIRE(dtype == RK_F32 || dtype == RK_F64, "rk_kernel_gram_bound: bad dtype %d", dtype);
+    RK_REQUIRE(X && center && bound && n > 0 && d > 0 && ldx >= d, "rk_kernel_gram_bound: bad arguments");
+    RK_REQUIRE(ell_vec != nullptr || ell_scalar > 0.0, "rk_kernel_gram_bound: lengthscale must be positive");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)ceil_div(n, 16));
+    if (dtype == RK_F32)
+        hipLaunchKernelGGL(gram_bound_kernel<float>, grid, dim3(256), 0, st, (const float*)X, n, ldx, d,
+                           (float)(1.0 / ell_scalar), (const float*)ell_vec, (const float*)center, (float*)bound);
+    else
+        hipLaunchKernelGGL(gram_bound_kernel<double>, grid, dim3(256), 0, st, (const double*)X, n, ldx, d,
+                           1.0 / ell_scalar, (const double*)ell_vec, (const double*)center, (double*)bound);
+    return launch_status("rk_kernel_gram_bound");
+}

@@ -16,6 +16,8 @@
 // column results to an (item, column) table; a finishing kernel adds them in a fixed order
 // (bitwise reproducible, no atomics) and applies alpha and the "+ reg v" term.
 // HBM traffic: the packed triangle once (+ ~1 % of partial tables) instead of the full square.
+#include <atomic>
+
 #include "rk_common.h"
 #include "rk_kerneltile.h"
 
@@ -379,22 +381,26 @@ static size_t symm_ws_bytes(int64_t n, int64_t k, int64_t first, int64_t stride)
     return (prow + pcol) * sizeof(T);
 }
 
-// resident workgroups of the persistent strip kernel on this device (cached per instantiation)
+// resident workgroups of the persistent strip kernel on the CURRENT device (cached per
+// instantiation and device ordinal; the slots are written with the same value by any thread)
 template <typename KernelT>
 static int64_t symm_resident_workgroups(KernelT kernel, int wg_per_cu) {
-    static int64_t cached = 0;
-    if (cached == 0) {
-        int per_cu = wg_per_cu, dev = 0, cus = 0;
+    static std::atomic<int64_t> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::atomic<int64_t>& slot = cached[dev & 63];
+    int64_t v = slot.load(std::memory_order_acquire);
+    if (v == 0) {
+        int per_cu = wg_per_cu, cus = 0;
         if (per_cu <= 0 &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, SYMM_THREADS, 0) != hipSuccess)
             per_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
         (void)hipGetLastError();
-        cached = (int64_t)(per_cu > 0 ? per_cu : 3) * (cus > 0 ? cus : 256);
+        v = (int64_t)(per_cu > 0 ? per_cu : 3) * (cus > 0 ? cus : 256);
+        slot.store(v, std::memory_order_release);
     }
-    return cached;
+    return v;
 }
 
 template <typename TS, typename T>

@@ -79,6 +79,28 @@ def _same_points(A1: torch.Tensor, A2: torch.Tensor) -> bool:
     )
 
 
+_UNSET = object()
+
+
+def _gram_center(kind: str, A1: torch.Tensor, A2: torch.Tensor, lengthscale, device=None):
+    """Centre for the matrix-core formulation of matrix-free products over (subsets of) the rows
+    of A1 and A2, or None (``HipBackend.gram_center``; one host read-back, so operators cache the
+    answer - the point sets of an operator never change)."""
+    if kind in ("laplace", "matern12") or A1.dtype != torch.float32 or A1.shape[1] > 64:
+        return None
+    be = get_backend()
+    if not hasattr(be, "gram_center"):
+        return None
+    dev = device if device is not None else A2.device
+    if torch.device(dev).type != "cuda":
+        return None
+    same = _same_points(A1, A2)
+    A2d = A2.to(dev)
+    A1d = A2d if same else A1.to(dev)
+    ell = lengthscale.to(dev) if isinstance(lengthscale, torch.Tensor) else lengthscale
+    return be.gram_center(A1d, A2d, ell)
+
+
 _PANEL_BYTES = 16 << 30  # temporary row-major panel for wide products in sympack mode (>= 512 GEMM tiles)
 _BLK_MATERIALIZE_BYTES = 1 << 30  # block oracles up to this size are materialised (SAP blocks)
 _SYM_MAX_COLS = 16      # beyond this many columns a product goes through panels + MFMA
@@ -167,6 +189,7 @@ class _KernelBlock:
         self.kind, self.A1, self.A2, self.config = kind, A1, A2, config
         self.scale = float(getattr(config, "const_scaling", 1.0))
         self._K = None
+        self._gc = _UNSET
         self._symmetric = A1 is A2 or (
             A1.data_ptr() == A2.data_ptr() and A1.shape == A2.shape and A1.stride() == A2.stride()
         )
@@ -184,12 +207,19 @@ class _KernelBlock:
             )
         return self._K
 
+    @property
+    def gram_center(self):
+        if self._gc is _UNSET:
+            self._gc = _gram_center(self.kind, self.A1, self.A2, self.config.lengthscale)
+        return self._gc
+
     def matmat(self, x, diag_shift=0.0, row0=0, alpha=1.0, beta=0.0, C=None):
         be = get_backend()
         if self.materialised:
             return be.matmat(self.K, x, alpha=alpha, beta=beta, C=C, diag_shift=diag_shift, row0=row0,
                              tag="kernel_shard_product")
-        y = be.kernel_matmat(self.kind, self.A1, self.A2, self.config.lengthscale, x, scale=self.scale)
+        y = be.kernel_matmat(self.kind, self.A1, self.A2, self.config.lengthscale, x, scale=self.scale,
+                             gram_center=self.gram_center)
         if diag_shift != 0.0:
             y = y + diag_shift * x[row0 : row0 + y.shape[0]]
         if alpha != 1.0 or beta != 0.0:
@@ -203,7 +233,8 @@ class _KernelBlock:
                 return be.matmat(self.K, x)
             return be.rmatmat(self.K, x)
         # K(A1, A2)^T = K(A2, A1)
-        return be.kernel_matmat(self.kind, self.A2, self.A1, self.config.lengthscale, x, scale=self.scale)
+        return be.kernel_matmat(self.kind, self.A2, self.A1, self.config.lengthscale, x, scale=self.scale,
+                                gram_center=self.gram_center)
 
     def release(self):
         self._K = None
@@ -278,11 +309,14 @@ class _KernelLinOp(TwoSidedLinOp, ScaleMixin):
         i2 = None if idx2 is None else idx2.to(self.device)
         rows = self._A1.shape[0] if idx1 is None else idx1.shape[0]
         cols = self._A2.shape[0] if idx2 is None else idx2.shape[0]
+        if getattr(self, "_gc", _UNSET) is _UNSET:  # once per operator: subsets inherit the bound
+            self._gc = _gram_center(self._kind, self._A1, self._A2, cfg.lengthscale)
+        gc = self._gc
 
         def matvec(x):
             return be.kernel_matmat(
                 self._kind, self._A1, self._A2, cfg.lengthscale, x, scale=self._scaling,
-                idx1=i1, idx2=i2,
+                idx1=i1, idx2=i2, gram_center=gc,
             )
 
         return LinOp(
@@ -527,6 +561,14 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
         return self._A1_bounds
 
     # -- oracles ---------------------------------------------------------------------------
+    def _gram_center_on(self, dev):
+        """Centre valid for every row of A1 and A2, resident on ``dev`` (cached per device)."""
+        cache = self.__dict__.setdefault("_gc_dev", {})
+        if dev not in cache:
+            cache[dev] = _gram_center(self._kind, self._A1, self._A2,
+                                      self._kernel_config_devices[dev].lengthscale, device=dev)
+        return cache[dev]
+
     def row_oracle(self, blk: torch.Tensor) -> _DistributedLinOp:
         """K(A1[blk], A2): column-distributed - shard i multiplies K(A1[blk], A2[cols_i]) with
         x[cols_i]; partial results are summed (base.py:408-447, utils.py:10-29)."""
@@ -540,9 +582,11 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
                 continue
             cfg = self._kernel_config_devices[dev]
             A1b = self._A1[blk.to(self._A1.device)].to(dev)  # gathered once per oracle
+            gc = self._gram_center_on(dev)
 
-            def matvec(x, A1b=A1b, A2c=A2c, cfg=cfg):
-                return be.kernel_matmat(self._kind, A1b, A2c, cfg.lengthscale, x, scale=self._scaling)
+            def matvec(x, A1b=A1b, A2c=A2c, cfg=cfg, gc=gc):
+                return be.kernel_matmat(self._kind, A1b, A2c, cfg.lengthscale, x, scale=self._scaling,
+                                        gram_center=gc)
 
             ops.append(LinOp(device=dev, shape=shape, matvec=matvec, matmat=matvec, dtype=self.dtype))
         return _DistributedLinOp(
@@ -574,9 +618,11 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
                 def matvec(x, Kb=Kb):
                     return be.matmat(Kb, x)
             else:
+                gc = self._gram_center_on(dev)
 
-                def matvec(x, A1c=A1c, A2b=A2b, cfg=cfg):
-                    return be.kernel_matmat(self._kind, A1c, A2b, cfg.lengthscale, x, scale=self._scaling)
+                def matvec(x, A1c=A1c, A2b=A2b, cfg=cfg, gc=gc):
+                    return be.kernel_matmat(self._kind, A1c, A2b, cfg.lengthscale, x, scale=self._scaling,
+                                            gram_center=gc)
 
             ops.append(LinOp(device=dev, shape=shape, matvec=matvec, matmat=matvec, dtype=self.dtype))
         return _DistributedLinOp(

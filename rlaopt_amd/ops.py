@@ -163,12 +163,55 @@ class HipBackend:
         _lib.check(rc, "rk_kernel_materialize")
         return out
 
-    def kernel_matmat(self, kind, X1, X2, lengthscale, V, scale=1.0, idx1=None, idx2=None):
+    def gram_center(self, X1, X2, lengthscale):
+        """Centre c (length-d tensor) for the matrix-core formulation of the matrix-free float32
+        product, or None when the data do not qualify: float32 only, d <= 64, and
+        max |(x - c) / ell|^2 <= RK_GRAM_MAX_NORM2 over the rows of X1 and X2 (include/rk.h).
+        One small device reduction and ONE host read-back: operators call it once per point set
+        (gathered subsets inherit the bound) and hand the result to ``kernel_matmat``."""
+        dev = _req(X1, X2)
+        if X1.dtype != torch.float32 or X2.dtype != torch.float32 or X1.shape[1] > 64:
+            return None
+        ell_vec, ell = None, 1.0
+        if isinstance(lengthscale, torch.Tensor):
+            ell_vec = lengthscale.to(device=dev, dtype=X1.dtype).contiguous()
+        else:
+            ell = float(lengthscale)
+        X2r, ld2 = _rowmajor(X2)
+        d = X2r.shape[1]
+        center = torch.empty(d, dtype=X1.dtype, device=dev)
+        bound = torch.zeros(1, dtype=X1.dtype, device=dev)
+        rc = self._lib.rk_kernel_center(_dt(X2r), _ptr(X2r), X2r.shape[0], ld2, d, _ptr(center), _stream(dev))
+        _lib.check(rc, "rk_kernel_center")
+        sets = [(X2r, ld2)]
+        if not (X1 is X2 or (X1.data_ptr() == X2.data_ptr() and X1.shape == X2.shape)):
+            sets.append(_rowmajor(X1))
+        for X, ld in sets:
+            rc = self._lib.rk_kernel_gram_bound(
+                _dt(X), _ptr(X), X.shape[0], ld, d, ell, _ptr(ell_vec), _ptr(center), _ptr(bound), _stream(dev)
+            )
+            _lib.check(rc, "rk_kernel_gram_bound")
+        return center if float(bound) <= _lib.GRAM_MAX_NORM2 else None
+
+    def kernel_matmat(self, kind, X1, X2, lengthscale, V, scale=1.0, idx1=None, idx2=None,
+                      gram_center="auto"):
         """scale * K(X1[idx1], X2[idx2]) @ V, matrix-free; wide V is processed in
-        16-column groups (each group recomputes the kernel entries)."""
+        16-column groups (each group recomputes the kernel entries).  ``gram_center``: the
+        tensor returned by :meth:`gram_center` for these point sets (matrix-core formulation),
+        None (direct-difference kernels), or "auto" = compute it here (one host read-back per
+        call: operators precompute it instead)."""
         dev, kid, X1, ld1, X2, ld2, ell, ell_vec, idx1, idx2, n1, n2 = self._kernel_common(
             kind, X1, X2, lengthscale, idx1, idx2
         )
+        if isinstance(gram_center, str):
+            if gram_center != "auto":
+                raise ValueError("gram_center must be a tensor, None or 'auto'")
+            gram_center = self.gram_center(X1, X2, lengthscale) if kind not in ("laplace", "matern12") else None
+        elif gram_center is not None:
+            _req(gram_center)
+            if gram_center.dtype != X1.dtype or gram_center.numel() != X1.shape[1]:
+                raise ValueError("gram_center must have one entry per feature and the dtype of the data")
+            gram_center = gram_center.contiguous()
         _req(V)
         V2, squeeze = _as2d(V)
         if V2.shape[0] != n2:
@@ -186,7 +229,7 @@ class HipBackend:
             rc = self._lib.rk_kernel_matmat(
                 _dt(X1), kid, _ptr(X1), n1, ld1, _ptr(idx1), _ptr(X2), n2, ld2, _ptr(idx2),
                 X1.shape[1], ell, _ptr(ell_vec), float(scale), V2.data_ptr() + c0 * es, kc, ldv,
-                out.data_ptr() + c0 * es, k, 0, _ptr(ws), wsn, _stream(dev),
+                out.data_ptr() + c0 * es, k, 0, _ptr(gram_center), _ptr(ws), wsn, _stream(dev),
             )
             _lib.check(rc, "rk_kernel_matmat")
         return out[:, 0] if squeeze else out
@@ -470,6 +513,48 @@ class HipBackend:
         _lib.check(rc, "rk_randn")
         return out
 
+
+def _device_of(args, kwargs):
+    for a in args:
+        if isinstance(a, torch.Tensor) and a.is_cuda:
+            return a.device
+    for a in kwargs.values():
+        if isinstance(a, torch.Tensor) and a.is_cuda:
+            return a.device
+    dev = kwargs.get("device")
+    for a in (dev, *args):
+        if isinstance(a, (torch.device, str)):
+            try:
+                a = torch.device(a)
+            except (RuntimeError, TypeError):
+                continue
+            if a.type == "cuda":
+                return a
+    return None
+
+
+def _guard_device(fn):
+    """Make the operands' device current for the duration of the call: the C side launches on the
+    stream it is given but sizes persistent grids / sets function attributes for the CURRENT
+    device, and a single process may drive several GPUs (``devices={cuda:0, cuda:1}``)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        dev = _device_of(args, kwargs)
+        if dev is None or dev.index is None or dev.index == torch.cuda.current_device():
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(self, *args, **kwargs)
+
+    return wrapped
+
+
+for _name in ("gram_center", "kernel_materialize", "kernel_matmat", "sympack_materialize", "symm_matmat",
+              "matmat", "rmatmat", "gemm", "gram_tn", "pcg_update_wr", "pcg_update_p", "axpby_cols",
+              "normal_pass", "small_solve", "sparse_sign_apply", "randn"):
+    setattr(HipBackend, _name, _guard_device(getattr(HipBackend, _name)))
+del _name
 
 _backend = None
 

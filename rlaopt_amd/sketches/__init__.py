@@ -181,13 +181,19 @@ class Sparse(Sketch):
     here the last one).  The structure is kept in row-sorted form; ``Omega @ A`` for a tensor A
     (the SkPre update) runs as a gather of rows of A (``rk_sparse_sign_apply``: zeta passes over
     A, no dense s x d matrix).  ``Omega_mat`` densifies on demand for every other use, like
-    the reference.  The draws use torch's device RNG (O(zeta d) work, outside the hot path)."""
+    the reference.  The draws use a torch device generator (O(zeta d) work, outside the hot path)
+    seeded through ``_draw_seed`` - broadcast from rank 0 like the Gaussian sketches - so that every
+    rank of a row-sharded operator builds the SAME embedding (each rank's own device RNG would
+    give the ranks different Omegas and an inconsistent all-reduced Nystrom core)."""
 
     def _generate_embedding(self):
         s, d, dev = self.s, self.d, self.device
         zeta = 8 if s >= 8 else s
-        signs = 2 * torch.bernoulli(torch.full((zeta, d), 0.5, dtype=self.dtype, device=dev)) - 1
-        rows = torch.randint(s, (zeta, d), device=dev)
+        seed, _offset = _draw_seed()
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(seed)
+        signs = 2 * torch.bernoulli(torch.full((zeta, d), 0.5, dtype=self.dtype, device=dev), generator=gen) - 1
+        rows = torch.randint(s, (zeta, d), device=dev, generator=gen)
         keep = torch.ones((zeta, d), dtype=torch.bool, device=dev)
         for t in range(zeta - 1):  # entry t is overwritten by a later draw on the same row
             keep[t] &= ~(rows[t + 1 :] == rows[t]).any(dim=0)

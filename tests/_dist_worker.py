@@ -153,6 +153,23 @@ def main():
         Wsum = W.clone()
         td.all_reduce(Wsum)
         torch.testing.assert_close(Wsum / size, W, rtol=1e-12, atol=1e-12)
+        # ---- every rank draws the SAME random embedding (seed broadcast from rank 0), although the
+        # ranks' own generators differ: gauss / ortho / sparse (sketches/*.py) ---------------------
+        torch.manual_seed(1000 + rank)  # ranks deliberately out of step
+        for name in ("sparse", "gauss", "ortho"):
+            sk = sketches.get_sketch(name, "right", 8, n, dt, cpu)
+            Om_mine = sk.Omega_mat.clone()
+            Om_sum = Om_mine.clone()
+            td.all_reduce(Om_sum)
+            torch.testing.assert_close(Om_sum / size, Om_mine, rtol=1e-12, atol=1e-14)
+        with torch.random.fork_rng():
+            torch.manual_seed(1000 + rank)
+            Wsp, logsp = LinSys(A, B, reg=reg).solve(
+                PCGConfig(device=cpu, max_iters=200, atol=0.0, rtol=1e-9,
+                          precond_config=NystromConfig(rank=r, rho=reg, sketch="sparse")),
+                torch.zeros_like(B), callback_freq=5)
+        ressp = torch.linalg.norm(B - (Kd @ Wsp + reg * Wsp), dim=0) / torch.linalg.norm(B, dim=0)
+        assert bool((ressp <= 1e-9).all()), ressp
         # ---- SPMD sketch-and-project (distributed row / block oracles, replicated iterates) --------
         from oracle import sap as osap
         from rlaopt_amd.solvers import SAPAccelConfig, SAPConfig

@@ -326,24 +326,138 @@ def test_normal_pass_unsupported_shapes(be):
 
 @pytest.mark.parametrize("n1,n2,d,k", [(129, 1000, 50, 10), (300, 515, 64, 1), (64, 128, 33, 16), (500, 2100, 8, 4)])
 def test_kernel_matmat_matrix_core_formulation(be, monkeypatch, n1, n2, d, k):
-    """The matrix-core formulation (default for float32 L2 kernels with d <= 64: S = X2 X1^T on the
-    fp32 MFMA, |x|^2 + |y|^2 - 2 S, kappa on the accumulators, Y^T += V^T P^T) against the oracle
-    and against the direct-difference kernels (RK_KMAT_MFMA=0), with and without index gathers."""
+    """The matrix-core formulation (float32 kernels smooth in the squared distance, d <= 64, data
+    inside the norm bound: S = X2' X1'^T on the fp32 MFMA, |x'|^2 + |y'|^2 - 2 S, kappa on the
+    accumulators, Y^T += V^T P^T) against the oracle and against the direct-difference kernels
+    (RK_KMAT_MFMA=0), with and without index gathers, scalar and per-feature lengthscales."""
     dt = torch.float32
     gen = torch.Generator().manual_seed(n1 + n2 + d)
     X1 = torch.randn(n1, d, dtype=dt, generator=gen) / d**0.5
     X2 = torch.randn(n2, d, dtype=dt, generator=gen) / d**0.5
     V = torch.randn(n2, k, dtype=dt, generator=gen)
     blk = torch.randperm(n2, generator=gen)[: min(n1, 97)]
-    for kind in ("rbf", "matern32"):
-        want = ok.kernel_matmat(kind, X1.double(), X2.double(), 0.8, V.double(), 1.5)
-        want_g = ok.kernel_matmat(kind, X2.double(), X2.double(), 0.8, V.double(), 1.5, idx1=blk)
+    blk2 = torch.randperm(n2, generator=gen)[: max(130, n2 // 2)]
+    ard = 0.6 + 0.4 * torch.rand(d, dtype=dt, generator=gen)
+    for kind, ls in (("rbf", 0.8), ("matern32", 0.8), ("rbf", ard), ("matern52", ard)):
+        ls64 = _ls64(ls)
+        lsd = ls.to(dev()) if isinstance(ls, torch.Tensor) else ls
+        want = ok.kernel_matmat(kind, X1.double(), X2.double(), ls64, V.double(), 1.5)
+        want_g = ok.kernel_matmat(kind, X2.double(), X2.double(), ls64, V.double(), 1.5, idx1=blk)
+        want_gg = ok.kernel_matmat(kind, X2.double(), X2.double(), ls64, V[: blk2.numel()].double(), 1.5,
+                                   idx1=blk, idx2=blk2)
+        assert be.gram_center(X1.to(dev()), X2.to(dev()), lsd) is not None
         monkeypatch.setenv("RK_KMAT_MFMA", "0")
-        base = be.kernel_matmat(kind, X1.to(dev()), X2.to(dev()), 0.8, V.to(dev()), scale=1.5)
+        base = be.kernel_matmat(kind, X1.to(dev()), X2.to(dev()), lsd, V.to(dev()), scale=1.5)
         monkeypatch.delenv("RK_KMAT_MFMA")
-        got = be.kernel_matmat(kind, X1.to(dev()), X2.to(dev()), 0.8, V.to(dev()), scale=1.5)
-        got_g = be.kernel_matmat(kind, X2.to(dev()), X2.to(dev()), 0.8, V.to(dev()), scale=1.5, idx1=blk.to(dev()))
+        got = be.kernel_matmat(kind, X1.to(dev()), X2.to(dev()), lsd, V.to(dev()), scale=1.5)
+        got_g = be.kernel_matmat(kind, X2.to(dev()), X2.to(dev()), lsd, V.to(dev()), scale=1.5, idx1=blk.to(dev()))
+        got_gg = be.kernel_matmat(kind, X2.to(dev()), X2.to(dev()), lsd, V[: blk2.numel()].to(dev()), scale=1.5,
+                                  idx1=blk.to(dev()), idx2=blk2.to(dev()))
         assert rel_err(got.cpu(), want) < LIM[dt]
         assert rel_err(got_g.cpu(), want_g) < LIM[dt]
+        assert rel_err(got_gg.cpu(), want_gg) < LIM[dt]
         assert rel_err(got.cpu(), base.cpu().double()) < LIM[dt]
         assert not torch.equal(got, base)  # (a different kernel really ran)
+
+
+def _columns(be, kind, X1d, X2d, ls, cols, idx1=None, idx2=None, **kw):
+    """Columns ``cols`` of K(X1[idx1], X2[idx2]) through the matrix-free product (unit vectors)."""
+    n2 = X2d.shape[0] if idx2 is None else idx2.numel()
+    E = torch.zeros(n2, len(cols), dtype=X1d.dtype, device=X1d.device)
+    E[torch.as_tensor(cols, device=X1d.device), torch.arange(len(cols), device=X1d.device)] = 1.0
+    return be.kernel_matmat(kind, X1d, X2d, ls, E, idx1=idx1, idx2=idx2, **kw)
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern32", "matern52"])
+@pytest.mark.parametrize("ell", ["scalar", "ard"])
+@pytest.mark.parametrize("data", ["unit", "offset"])
+def test_matrix_core_formulation_entrywise_on_the_diagonal(be, monkeypatch, kind, ell, data):
+    """ENTRY-WISE agreement of the matrix-core formulation with the direct-difference evaluation
+    (``kernel_materialize``: what pykeops computes) for X1 is X2 - the diagonal K(x, x) = 1, where
+    |x|^2 + |y|^2 - 2 x.y cancels completely - on centred unit-norm data and on un-centred data
+    (mean 10, std 1, lengthscale 8: without the centring of the panels the expansion is off by
+    1e-2), with scalar and per-feature lengthscales, with and without index gathers."""
+    dt = torch.float32
+    n, d, k = 700, 64, 16
+    gen = torch.Generator().manual_seed(11)
+    if data == "unit":
+        X = torch.randn(n, d, dtype=dt, generator=gen) / d**0.5
+        base_ell = 1.0
+    else:
+        X = 10.0 + torch.randn(n, d, dtype=dt, generator=gen)
+        base_ell = 8.0
+    ls = base_ell if ell == "scalar" else (base_ell * (0.75 + 0.5 * torch.rand(d, dtype=dt, generator=gen))).to(dev())
+    Xd = X.to(dev())
+    gc = be.gram_center(Xd, Xd, ls)
+    assert gc is not None  # the data qualify: the matrix-core kernel is the one under test
+    K = be.kernel_materialize(kind, Xd, Xd, ls)
+    cols = list(range(0, n, n // k))[:k]
+    got = _columns(be, kind, Xd, Xd, ls, cols, gram_center=gc)
+    monkeypatch.setenv("RK_KMAT_MFMA", "0")
+    direct = _columns(be, kind, Xd, Xd, ls, cols, gram_center=gc)
+    monkeypatch.delenv("RK_KMAT_MFMA")
+    assert not torch.equal(got, direct)  # two different kernels ran
+    torch.testing.assert_close(direct, K[:, cols], rtol=0, atol=2e-6)
+    torch.testing.assert_close(got, K[:, cols], rtol=0, atol=2e-5)  # reference tolerance: 1e-4
+    diag = got[cols, torch.arange(len(cols))]
+    torch.testing.assert_close(diag, torch.ones_like(diag), rtol=0, atol=2e-5)
+    # gathered: block oracle K(X[blk], X[blk]) (kernels/base.py:104-128), diagonal included
+    blk = torch.randperm(n, generator=gen)[:300].to(dev())
+    Kb = K[blk][:, blk]
+    cb = list(range(0, 300, 300 // k))[:k]
+    got_b = _columns(be, kind, Xd, Xd, ls, cb, idx1=blk, idx2=blk, gram_center=gc)
+    torch.testing.assert_close(got_b, Kb[:, cb], rtol=0, atol=2e-5)
+
+
+def test_matrix_core_formulation_is_declined_when_unsafe(be, monkeypatch):
+    """Matern-1/2 (not smooth in the squared distance), data whose centred norms exceed
+    RK_GRAM_MAX_NORM2, and a missing centre all run the direct-difference kernels: results are
+    bitwise those of RK_KMAT_MFMA=0."""
+    from rlaopt_amd import _lib
+
+    dt = torch.float32
+    gen = torch.Generator().manual_seed(5)
+    n, d = 400, 32
+    X = (torch.randn(n, d, dtype=dt, generator=gen) / d**0.5).to(dev())
+    V = torch.randn(n, 3, dtype=dt, generator=gen).to(dev())
+    wide = (torch.randn(n, d, dtype=dt, generator=gen) * 3.0).to(dev())  # |x|^2 ~ 9 d = 288 > 32
+    assert be.gram_center(X, X, 1.0) is not None
+    assert be.gram_center(wide, wide, 1.0) is None
+    assert be.gram_center(wide, wide, 10.0) is not None  # the bound is on |x / ell|^2
+    assert be.gram_center(X, wide, 1.0) is None  # both point sets count
+    assert be.gram_center(X.double(), X.double(), 1.0) is None
+    bad = X.clone()
+    bad[7, 3] = float("nan")
+    assert be.gram_center(bad, bad, 1.0) is None
+    assert _lib.GRAM_MAX_NORM2 == 32.0
+    gc = be.gram_center(X, X, 1.0)
+    cases = [("matern12", X, gc), ("rbf", X, None), ("rbf", wide, "auto"), ("laplace", X, gc)]
+    for kind, P, c in cases:
+        got = be.kernel_matmat(kind, P, P, 1.0, V, gram_center=c)
+        monkeypatch.setenv("RK_KMAT_MFMA", "0")
+        want = be.kernel_matmat(kind, P, P, 1.0, V, gram_center=c)
+        monkeypatch.delenv("RK_KMAT_MFMA")
+        assert torch.equal(got, want), kind
+    with pytest.raises(ValueError):
+        be.kernel_matmat("rbf", X, X, 1.0, V, gram_center=gc[:5])
+
+
+def test_gram_center_and_bound_values(be):
+    """rk_kernel_center / rk_kernel_gram_bound against torch: sampled mean (stride n // 4096) and
+    the exact maximum of the centred, scaled squared norms."""
+    gen = torch.Generator().manual_seed(3)
+    for n, d in ((1000, 7), (10000, 64), (5, 3)):
+        X = (2.0 + torch.randn(n, d, dtype=torch.float32, generator=gen)).to(dev())
+        ell = (0.5 + torch.rand(d, dtype=torch.float32, generator=gen)).to(dev())
+        stride = n // 4096 if n > 4096 else 1
+        mean = X[::stride].double().mean(0)
+        bound_ref = float((((X.double() - mean) / ell.double()) ** 2).sum(1).max())
+        lib = be._lib
+        center = torch.empty(d, dtype=torch.float32, device=dev())
+        bound = torch.zeros(1, dtype=torch.float32, device=dev())
+        assert lib.rk_kernel_center(0, X.data_ptr(), n, d, d, center.data_ptr(), None) == 0
+        assert lib.rk_kernel_gram_bound(0, X.data_ptr(), n, d, d, 1.0, ell.data_ptr(), center.data_ptr(),
+                                        bound.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        torch.testing.assert_close(center.double().cpu(), mean.cpu(), rtol=1e-5, atol=1e-6)
+        assert abs(float(bound) - bound_ref) <= 1e-4 * bound_ref
