@@ -1,0 +1,356 @@
+// Fused kernel-matrix product with the distance contraction on the DOUBLE-RATE bf16 matrix cores of
+// gfx950, at float32 accuracy (float32 data, kernels smooth in the squared distance, d <= 64):
+//
+//     Y[i][c] = scale * sum_j kappa(|x'_i|^2 + |y'_j|^2 - 2 x'_i . y'_j) V[j][c]
+//
+// Every centred, scaled coordinate x' (see rk_kernelmfma.hip for the centring and the norm bound
+// the caller vouches for) is split EXACTLY into three bf16 numbers x' = h + m + l (8 significant
+// bits each: h = bf16(x'), m = bf16(x' - h), l = bf16(x' - h - m); the remainder is below 2^-24
+// |x'|).  The dot product is the sum of the six partial products
+//     h.h + (h.m + m.h) + (m.m + h.l + l.h)
+// - products of bf16 numbers are exact in float32 and the matrix cores accumulate in float32; the
+// three dropped terms (m.l, l.m, l.l) are below 2^-23 |x'||y'|, the rounding level of a float32 dot
+// product.  v_mfma_f32_16x16x32_bf16 retires 16 384 flop in 16 cycles per SIMD - 16 x the rate of
+// v_mfma_f32_32x32x2_f32 (4 096 flop in 64 cycles) - so six of them still cost 2.7 x less matrix-
+// core time than the float32 formulation (rk_kernelmfma.hip), and a d <= 32 system needs one k-step.
+//
+// Prologue (gram_split_kernel): both point sets are gathered, centred, scaled, split and written
+// once per call as 64-point "images" - per image 3 splits x 64 points x 64 features (zero padded)
+// of bf16 = 24 KiB, rows XOR-swizzled in 16-byte chunks so that a wave's ds_read_b128 of an MFMA
+// operand (16 points x 8 features per lane group) is bank-conflict free - together with |x'|^2.
+// Main kernel: workgroup = 4 waves, each owns 32 points of X1 (two 16-wide blocks) whose B
+// operands stay in 48 registers for the whole kernel; the workgroup walks 64-point tiles of X2
+// through a double-buffered LDS image (register-staged prefetch two tiles ahead, one barrier per
+// tile).  Per tile and wave: S^T = X2 X1^T (4 x 2 blocks of 16 x 16, 6 MFMAs per block and
+// k-step), P = kappa(|x|^2 + |y|^2 - 2 S) on the accumulators, then Y^T += V^T P^T either on the
+// VALU (k <= 4) or on the float32 matrix cores (v_mfma_f32_16x16x4_f32: P is the B operand as it
+// sits in the accumulators - element v of a lane is P[j = 4 (lane / 16) + v][i = lane % 16] - and
+// 16 right-hand sides fill the instruction).  No cross-wave reduction: a wave owns its i-range.
+#include "rk_common.h"
+#include "rk_kerneltile.h"
+
+namespace rk {
+
+constexpr int BX_TJ = 64;                       // X2 points per tile (= points per image)
+constexpr int BX_TI = 128;                      // X1 points per workgroup (4 waves x 32)
+constexpr int BX_D = 64;                        // features per point in an image
+constexpr int BX_SPLIT = BX_TJ * BX_D * 2;      // bytes of one split of one image (8 KiB)
+constexpr int BX_IMG = 3 * BX_SPLIT;            // bytes of one image (24 KiB)
+constexpr int BX_LDV = 20;                      // stride of the V tile rows (conflict-free A operand reads)
+constexpr int BX_FOLD = 32;                     // tiles between folds of the running sums (2 048 columns)
+
+typedef __bf16 bx_frag __attribute__((ext_vector_type(8)));
+typedef float bx_acc __attribute__((ext_vector_type(4)));
+typedef unsigned int bx_u4 __attribute__((ext_vector_type(4)));
+
+// byte offset of 16-byte chunk c (8 features) of point r inside one split of an image
+__device__ __forceinline__ int bx_chunk(int r, int c) { return r * (BX_D * 2) + ((c ^ ((r >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ unsigned bx_bf16_rn(float x) {  // round to nearest even, finite x
+    unsigned u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+// One thread per (point, 8-feature chunk): gather, centre, scale, split, swizzle, |x'|^2.
+// Points n .. npad - 1 (padding of the last image) are written as zeros.
+__global__ void __launch_bounds__(256)
+gram_split_kernel(const float* __restrict__ X, int64_t ldx, const int64_t* __restrict__ idx, int64_t n,
+                  int64_t npad, int64_t d, const float* __restrict__ iw, const float* __restrict__ muw,
+                  unsigned char* __restrict__ img, float* __restrict__ norms) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t p = g >> 3;
+    const int c = (int)(g & 7);
+    if (p >= npad) return;  // (whole groups of 8 lanes: npad * 8 is a multiple of 64)
+    const bool live = p < n;
+    const float* row = live ? X + (idx ? idx[p] : p) * ldx : nullptr;
+    unsigned hs[8], ms[8], ls[8];
+    float ss = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int f = c * 8 + u;
+        const float x = (live && f < d) ? fmaf(row[f], iw[f], -muw[f]) : 0.f;
+        ss += x * x;
+        const unsigned h = bx_bf16_rn(x);
+        const float r1 = x - __uint_as_float(h << 16);   // exact
+        const unsigned m = bx_bf16_rn(r1);
+        const float r2 = r1 - __uint_as_float(m << 16);  // exact
+        hs[u] = h; ms[u] = m; ls[u] = bx_bf16_rn(r2);
+    }
+    ss += __shfl_xor(ss, 1);
+    ss += __shfl_xor(ss, 2);
+    ss += __shfl_xor(ss, 4);
+    if (live && c == 0) norms[p] = ss;
+    const int r = (int)(p & (BX_TJ - 1));
+    unsigned char* dst = img + (p >> 6) * BX_IMG + bx_chunk(r, c);
+    auto pack = [](const unsigned* e) {
+        bx_u4 o;
+        o.x = e[0] | (e[1] << 16); o.y = e[2] | (e[3] << 16); o.z = e[4] | (e[5] << 16); o.w = e[6] | (e[7] << 16);
+        return o;
+    };
+    *reinterpret_cast<bx_u4*>(dst) = pack(hs);
+    *reinterpret_cast<bx_u4*>(dst + BX_SPLIT) = pack(ms);
+    *reinterpret_cast<bx_u4*>(dst + 2 * BX_SPLIT) = pack(ls);
+}
+
+template <bool RBF>
+__device__ __forceinline__ float bx_kappa(int kind, float s, float w, float rbf_c) {
+    if constexpr (RBF) return __builtin_amdgcn_exp2f(s * rbf_c);  // exp(-s w^2 / 2)
+    else return kernel_value<float>(kind, s, w);
+}
+
+constexpr size_t BX_SMEM_BYTES = 2 * BX_IMG + 2 * BX_TJ * BX_LDV * sizeof(float) + 2 * BX_TJ * sizeof(float);
+
+// KV = 0: second product on the float32 matrix cores (k <= 16); KV = 1 / 2 / 4: on the VALU (k <= KV)
+template <bool RBF, int KV>
+__global__ void __launch_bounds__(256, 2)
+kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, const unsigned char* __restrict__ img2,
+                          int64_t n1, int64_t n2, int nks, float w, float scale, const float* __restrict__ nx,
+                          const float* __restrict__ ny, const float* __restrict__ V, int k, int64_t ldv,
+                          int64_t tiles_per_seg, float* __restrict__ part, float* __restrict__ Y, int64_t ldy,
+                          int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* XB = smem;                                                  // [2][BX_IMG]
+    float* VS = reinterpret_cast<float*>(smem + 2 * BX_IMG);                   // [2][BX_TJ][BX_LDV]
+    float* NY = VS + 2 * BX_TJ * BX_LDV;                                       // [2][BX_TJ]
+    const float rbf_c = -0.5f * w * w * 1.4426950408889634f;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int64_t i0 = (int64_t)blockIdx.x * BX_TI;
+    const int64_t ntile = (n2 + BX_TJ - 1) / BX_TJ;
+    const int64_t t_lo = (int64_t)blockIdx.y * tiles_per_seg;
+    const int64_t t_hi = (t_lo + tiles_per_seg < ntile) ? t_lo + tiles_per_seg : ntile;
+
+    // ---- this wave's X1 operands: 2 blocks of 16 points x 2 k-steps x 3 splits, resident ----------
+    bx_frag bh[2][2], bm[2][2], bl[2][2];
+    float nxr[2];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+        const int64_t ip = i0 + wave * 32 + ib * 16 + lr;  // < round_up(n1, 128): the images exist
+        const int r = (int)(ip & (BX_TJ - 1));
+        const unsigned char* base = img1 + (ip >> 6) * BX_IMG;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bx_u4 z = {0u, 0u, 0u, 0u};
+            bx_u4 h = z, m = z, l = z;
+            if (ks < nks) {
+                const unsigned char* src = base + bx_chunk(r, 4 * ks + lq);
+                h = *reinterpret_cast<const bx_u4*>(src);
+                m = *reinterpret_cast<const bx_u4*>(src + BX_SPLIT);
+                l = *reinterpret_cast<const bx_u4*>(src + 2 * BX_SPLIT);
+            }
+            bh[ib][ks] = __builtin_bit_cast(bx_frag, h);
+            bm[ib][ks] = __builtin_bit_cast(bx_frag, m);
+            bl[ib][ks] = __builtin_bit_cast(bx_frag, l);
+        }
+        nxr[ib] = ip < n1 ? nx[ip] : 0.f;
+    }
+
+    // ---- tile staging: registers -> LDS (the image is copied linearly: it is stored swizzled) -------
+    bx_u4 pre[6];
+    float vr[4], nyr;
+    auto load_tile = [&](int64_t t) {
+        const bx_u4* src = reinterpret_cast<const bx_u4*>(img2 + t * BX_IMG);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) pre[q] = src[tid + 256 * q];
+        const int64_t j = t * BX_TJ + (tid >> 2);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = (tid & 3) * 4 + u;
+            vr[u] = (j < n2 && c < k) ? V[j * ldv + c] : 0.f;
+        }
+        nyr = (tid < BX_TJ && t * BX_TJ + tid < n2) ? ny[t * BX_TJ + tid] : 0.f;
+    };
+    auto store_tile = [&](int buf) {
+        bx_u4* dst = reinterpret_cast<bx_u4*>(XB + buf * BX_IMG);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) dst[tid + 256 * q] = pre[q];
+        float* vs = VS + buf * BX_TJ * BX_LDV + (tid >> 2) * BX_LDV + (tid & 3) * 4;
+        *reinterpret_cast<float4*>(vs) = make_float4(vr[0], vr[1], vr[2], vr[3]);
+        if (tid < BX_TJ) NY[buf * BX_TJ + tid] = nyr;
+    };
+
+    // running sums, two-level (folded every BX_FOLD tiles)
+    bx_acc yacc[2], ytot[2];
+    constexpr int KVN = KV > 0 ? KV : 1;
+    float yv[2][KVN], yvt[2][KVN];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { yacc[ib][v] = 0.f; ytot[ib][v] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < KVN; ++c) yv[ib][c] = yvt[ib][c] = 0.f;
+    }
+
+    if (t_lo < t_hi) {
+        load_tile(t_lo);
+        store_tile(0);
+        if (t_lo + 1 < t_hi) load_tile(t_lo + 1);
+    }
+    __syncthreads();
+    for (int64_t t = t_lo; t < t_hi; ++t) {
+        const int buf = (int)((t - t_lo) & 1);
+        if (t + 1 < t_hi) store_tile(buf ^ 1);  // tile t + 1 (loaded one iteration ago) -> the other buffer
+        if (t + 2 < t_hi) load_tile(t + 2);     // in flight during this tile's arithmetic
+        if (((t - t_lo) & (BX_FOLD - 1)) == BX_FOLD - 1) {
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                ytot[ib] += yacc[ib];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) yacc[ib][v] = 0.f;
+#pragma unroll
+                for (int c = 0; c < KVN; ++c) { yvt[ib][c] += yv[ib][c]; yv[ib][c] = 0.f; }
+            }
+        }
+        const unsigned char* xb = XB + buf * BX_IMG;
+        const float* vsb = VS + buf * BX_TJ * BX_LDV;
+        const float* nyb = NY + buf * BX_TJ;
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            // ---- S^T block row jb: 16 points of X2 against this wave's 2 x 16 points of X1 -------
+            bx_acc acc[2];
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[ib][v] = 0.f;
+            const int r = jb * 16 + lr;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks < nks) {
+                    const unsigned char* src = xb + bx_chunk(r, 4 * ks + lq);
+                    const bx_frag ah = *reinterpret_cast<const bx_frag*>(src);
+                    const bx_frag am = *reinterpret_cast<const bx_frag*>(src + BX_SPLIT);
+                    const bx_frag al = *reinterpret_cast<const bx_frag*>(src + 2 * BX_SPLIT);
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib) {  // small terms first
+                        acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ib][ks], acc[ib], 0, 0, 0);
+                        acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ib][ks], acc[ib], 0, 0, 0);
+                        acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[ib][ks], acc[ib], 0, 0, 0);
+                        acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[ib][ks], acc[ib], 0, 0, 0);
+                        acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[ib][ks], acc[ib], 0, 0, 0);
+                        acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ib][ks], acc[ib], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- P = kappa(|x|^2 + |y|^2 - 2 S); Y^T += V^T P^T ------------------------------------
+            const float4 ny4 = *reinterpret_cast<const float4*>(nyb + jb * 16 + 4 * lq);
+            const float nyv[4] = {ny4.x, ny4.y, ny4.z, ny4.w};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float p[2];
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) {
+                    float s = nxr[ib] + nyv[v] - 2.f * acc[ib][v];
+                    s = s > 0.f ? s : 0.f;
+                    p[ib] = bx_kappa<RBF>(kind, s, w, rbf_c);
+                }
+                const float* vj = vsb + (jb * 16 + 4 * lq + v) * BX_LDV;
+                if constexpr (KV == 0) {
+                    const float av = vj[lr];  // A operand: V[j = 4 (lane / 16) + v][rhs = lane % 16]
+#pragma unroll
+                    for (int ib = 0; ib < 2; ++ib)
+                        yacc[ib] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, p[ib], yacc[ib], 0, 0, 0);
+                } else {
+                    float vv[KV];
+                    if constexpr (KV == 4) {
+                        const float4 q = *reinterpret_cast<const float4*>(vj);
+                        vv[0] = q.x; vv[1] = q.y; vv[2] = q.z; vv[3] = q.w;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < KV; ++c) vv[c] = vj[c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < KV; ++c)
+#pragma unroll
+                        for (int ib = 0; ib < 2; ++ib) yv[ib][c] += p[ib] * vv[c];
+                }
+            }
+        }
+        __syncthreads();  // tile t + 1 is in LDS; every wave is done with tile t's buffer
+    }
+    // ---- this wave's 32 rows of Y: through LDS as [i (128)][rhs (16)], then coalesced out ---------------
+    float* yl = reinterpret_cast<float*>(XB);  // (all reads of the last tile are behind the barrier above)
+    if constexpr (KV == 0) {
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)  // element v: rhs 4 (lane / 16) + v, i = lane % 16
+                yl[(wave * 32 + ib * 16 + lr) * 16 + 4 * lq + v] = ytot[ib][v] + yacc[ib][v];
+    } else {
+        // the 4 lane groups hold partial sums over their j's: [i][rhs][group]
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int c = 0; c < KV; ++c)
+                yl[((wave * 32 + ib * 16 + lr) * KV + c) * 4 + lq] = yvt[ib][c] + yv[ib][c];
+    }
+    __syncthreads();
+    for (int e = tid; e < BX_TI * k; e += 256) {
+        const int il = e / k, c = e - il * k;
+        float sum;
+        if constexpr (KV == 0) {
+            sum = yl[il * 16 + c];
+        } else {
+            const float4 q = *reinterpret_cast<const float4*>(yl + (il * KV + c) * 4);
+            sum = (q.x + q.y) + (q.z + q.w);
+        }
+        const int64_t i = i0 + il;
+        if (i >= n1) continue;
+        if (part != nullptr) {
+            part[((int64_t)blockIdx.y * n1 + i) * k + c] = sum;
+        } else {
+            const float o = scale * sum;
+            if (accumulate) Y[i * ldy + c] += o;
+            else Y[i * ldy + c] = o;
+        }
+    }
+}
+
+// workspace behind the partial sums: affine map (2 x 64 floats), |x'|^2 of both sets, the images
+size_t bx_aux_bytes(int64_t n1, int64_t n2) {
+    const size_t fl = (size_t)round_up((2 * 64 + n1 + n2) * (int64_t)sizeof(float), 256);
+    return fl + (size_t)(round_up(n1, BX_TI) / BX_TJ + round_up(n2, BX_TJ) / BX_TJ) * BX_IMG;
+}
+
+void gram_prep_launch(const float* center, const float* ell_vec, int64_t d, float* iw, float* muw, hipStream_t st);
+
+int launch_kmatmat_bf16x3(int kind, const float* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
+                          const float* X2, int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d, float w,
+                          const float* ell_vec, const float* center, float scale, const float* V, int k,
+                          int64_t ldv, int64_t S, int64_t tiles_per_seg, void* aux, float* part, float* Y,
+                          int64_t ldy, int accumulate, hipStream_t st) {
+    float* iw = static_cast<float*>(aux);
+    float* muw = iw + 64;
+    float* nxp = muw + 64;
+    float* nyp = nxp + n1;
+    unsigned char* img1 = static_cast<unsigned char*>(aux) + round_up((2 * 64 + n1 + n2) * (int64_t)sizeof(float), 256);
+    const int64_t n1pad = round_up(n1, BX_TI), n2pad = round_up(n2, BX_TJ);
+    unsigned char* img2 = img1 + (n1pad / BX_TJ) * BX_IMG;
+    gram_prep_launch(center, ell_vec, d, iw, muw, st);
+    hipLaunchKernelGGL(gram_split_kernel, dim3((unsigned)ceil_div(n1pad * 8, 256)), dim3(256), 0, st, X1, ldx1,
+                       idx1, n1, n1pad, d, iw, muw, img1, nxp);
+    hipLaunchKernelGGL(gram_split_kernel, dim3((unsigned)ceil_div(n2pad * 8, 256)), dim3(256), 0, st, X2, ldx2,
+                       idx2, n2, n2pad, d, iw, muw, img2, nyp);
+    const int nks = d <= 32 ? 1 : 2;
+    dim3 grid((unsigned)ceil_div(n1, BX_TI), (unsigned)S);
+#define RK_BX(RBFV, KVV)                                                                                   \
+    hipLaunchKernelGGL((kmat_matmat_bf16x3_kernel<RBFV, KVV>), grid, dim3(256), BX_SMEM_BYTES, st, kind,   \
+                       img1, img2, n1, n2, nks, w, scale, nxp, nyp, V, k, ldv, tiles_per_seg, part, Y, ldy, \
+                       accumulate)
+#define RK_BX_K(RBFV)                                                                                      \
+    do {                                                                                                   \
+        if (k == 1) RK_BX(RBFV, 1);                                                                        \
+        else if (k == 2) RK_BX(RBFV, 2);                                                                   \
+        else if (k <= 4) RK_BX(RBFV, 4);                                                                   \
+        else RK_BX(RBFV, 0);                                                                               \
+    } while (0)
+    if (kind == RK_RBF) RK_BX_K(true);
+    else RK_BX_K(false);
+#undef RK_BX
+#undef RK_BX_K
+    return launch_status("rk_kernel_matmat(bf16x3)");
+}
+
+}  // namespace rk

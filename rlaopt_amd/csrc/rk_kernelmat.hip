@@ -660,6 +660,33 @@ static bool kmat_use_mfma(bool is_f32, int kind, const void* center, int64_t d, 
     return !(e != nullptr && e[0] == '0');
 }
 
+// rk_kernelbf16.hip: the same formulation with the distance contraction on the bf16 matrix cores
+// (three-way bf16 split of every coordinate, six partial products: float32 accuracy at 2.7 x less
+// matrix-core time).  RK_KMAT_BF16X3=0 (read per call) keeps the float32 MFMA kernel.
+size_t bx_aux_bytes(int64_t n1, int64_t n2);
+int launch_kmatmat_bf16x3(int kind, const float* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
+                          const float* X2, int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d, float w,
+                          const float* ell_vec, const float* center, float scale, const float* V, int k,
+                          int64_t ldv, int64_t S, int64_t tiles_per_seg, void* aux, float* part, float* Y,
+                          int64_t ldy, int accumulate, hipStream_t st);
+
+static bool kmat_use_bf16x3() {
+    const char* e = getenv("RK_KMAT_BF16X3");
+    return !(e != nullptr && e[0] == '0');
+}
+
+static KMPlan plan_kmatmat_bf16(int64_t n1, int64_t n2) {
+    const int64_t row_blocks = ceil_div(n1, 128);
+    const int64_t ntile = ceil_div(n2, 64);
+    int64_t S = ceil_div(4096, row_blocks);  // 512 workgroups are resident: >= 8 rounds (short tail)
+    if (S > ntile / 8) S = ntile / 8;        // >= 8 column tiles per workgroup
+    if (S < 1) S = 1;
+    KMPlan p;
+    p.tiles_per_seg = ceil_div(ntile, S);
+    p.S = ceil_div(ntile, p.tiles_per_seg);
+    return p;
+}
+
 static KMPlan plan_kmatmat_mfma(int64_t n1, int64_t n2) {
     const int64_t row_blocks = ceil_div(n1, 128);
     const int64_t ntile = ceil_div(n2, 128);
@@ -687,6 +714,23 @@ static int kmatmat_impl(int kind, const T* X1, int64_t n1, int64_t ldx1, const i
                         size_t ws_bytes, hipStream_t st) {
     const T w = ell_vec ? T(1) : T(1.0 / ell);
     if constexpr (sizeof(T) == 4) {
+        if (kmat_use_mfma(true, kind, gram_center, d, n1, n2) && kmat_use_bf16x3()) {
+            const KMPlan pb = plan_kmatmat_bf16(n1, n2);
+            const size_t off = kmat_norms_offset(pb.S, n1, k);
+            const size_t need = off + bx_aux_bytes(n1, n2);
+            if (ws == nullptr || ws_bytes < need) {
+                set_error("rk_kernel_matmat: workspace %zu B < required %zu B", ws_bytes, need);
+                return RK_ERR_WORKSPACE;
+            }
+            float* partb = pb.S > 1 ? static_cast<float*>(ws) : nullptr;
+            int rcb = launch_kmatmat_bf16x3(kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d, (float)w, ell_vec,
+                                            gram_center, (float)scale, V, (int)k, ldv, pb.S, pb.tiles_per_seg,
+                                            static_cast<char*>(ws) + off, partb, Y, ldy, accumulate, st);
+            if (rcb != RK_OK || partb == nullptr) return rcb;
+            hipLaunchKernelGGL((kmat_matmat_finish<T>), dim3((unsigned)ceil_div(n1 * k, 256)), dim3(256),
+                               0, st, partb, (int)pb.S, n1, (int)k, (T)scale, Y, ldy, accumulate);
+            return launch_status("rk_kernel_matmat(finish)");
+        }
         if (kmat_use_mfma(true, kind, gram_center, d, n1, n2)) {
             const KMPlan pm = plan_kmatmat_mfma(n1, n2);
             const size_t off = kmat_norms_offset(pm.S, n1, k);
@@ -800,6 +844,9 @@ extern "C" size_t rk_kernel_matmat_ws_bytes(int dtype, int64_t n1, int64_t n2, i
         const KMPlan pm = plan_kmatmat_mfma(n1, n2);
         const size_t m = kmat_norms_offset(pm.S, n1, k) + kmat_norms_bytes(n1, n2);
         if (m > bytes) bytes = m;
+        const KMPlan pb = plan_kmatmat_bf16(n1, n2);
+        const size_t b = kmat_norms_offset(pb.S, n1, k) + bx_aux_bytes(n1, n2);
+        if (b > bytes) bytes = b;
     }
     return bytes;
 }

@@ -58,6 +58,11 @@ __global__ void gram_prep_kernel(const float* __restrict__ center, const float* 
     muw[c] = b;
 }
 
+void gram_prep_launch(const float* center, const float* ell_vec, int64_t d, float* iw, float* muw,
+                      hipStream_t st) {
+    hipLaunchKernelGGL(gram_prep_kernel, dim3(1), dim3(MF_D), 0, st, center, ell_vec, d, iw, muw);
+}
+
 // |row'|^2 of gathered, centred, scaled rows: out[p] = sum_c (X[row(p)][c] iw[c] - muw[c])^2.
 // 16 lanes (one DPP row) per point, the features strided over them: a wave reads 4 rows in
 // 64-byte runs instead of 64 rows 4 bytes each
