@@ -26,6 +26,8 @@
 // VALU (k <= 4) or on the float32 matrix cores (v_mfma_f32_16x16x4_f32: P is the B operand as it
 // sits in the accumulators - element v of a lane is P[j = 4 (lane / 16) + v][i = lane % 16] - and
 // 16 right-hand sides fill the instruction).  No cross-wave reduction: a wave owns its i-range.
+#include <stdlib.h>
+
 #include "rk_common.h"
 #include "rk_kerneltile.h"
 
@@ -53,7 +55,7 @@ __device__ __forceinline__ unsigned bx_bf16_rn(float x) {  // round to nearest e
 }
 
 // One thread per (point, 8-feature chunk): gather, centre, scale, split, swizzle, |x'|^2.
-// Points n .. npad - 1 (padding of the last image) are written as zeros.
+// Points n .. npad - 1 (padding of the last image) are written as zeros; `norms` has npad entries.
 __global__ void __launch_bounds__(256)
 gram_split_kernel(const float* __restrict__ X, int64_t ldx, const int64_t* __restrict__ idx, int64_t n,
                   int64_t npad, int64_t d, const float* __restrict__ iw, const float* __restrict__ muw,
@@ -80,7 +82,8 @@ gram_split_kernel(const float* __restrict__ X, int64_t ldx, const int64_t* __res
     ss += __shfl_xor(ss, 1);
     ss += __shfl_xor(ss, 2);
     ss += __shfl_xor(ss, 4);
-    if (live && c == 0) norms[p] = ss;
+    // padding points get a huge |x'|^2: their kernel value is exactly 0 whatever V holds there
+    if (c == 0) norms[p] = live ? ss : 1e24f;
     const int r = (int)(p & (BX_TJ - 1));
     unsigned char* dst = img + (p >> 6) * BX_IMG + bx_chunk(r, c);
     auto pack = [](const unsigned* e) {
@@ -93,19 +96,17 @@ gram_split_kernel(const float* __restrict__ X, int64_t ldx, const int64_t* __res
     *reinterpret_cast<bx_u4*>(dst + 2 * BX_SPLIT) = pack(ls);
 }
 
-template <bool RBF>
-__device__ __forceinline__ float bx_kappa(int kind, float s, float w, float rbf_c) {
-    if constexpr (RBF) return __builtin_amdgcn_exp2f(s * rbf_c);  // exp(-s w^2 / 2)
-    else return kernel_value<float>(kind, s, w);
-}
-
 constexpr size_t BX_SMEM_BYTES = 2 * BX_IMG + 2 * BX_TJ * BX_LDV * sizeof(float) + 2 * BX_TJ * sizeof(float);
 
 // KV = 0: second product on the float32 matrix cores (k <= 16); KV = 1 / 2 / 4: on the VALU (k <= KV)
-template <bool RBF, int KV>
+// NKS = k-steps of 32 features (1: d <= 32, 2: d <= 64)
+// (A hand-ordered instruction stream - operand reads one step ahead, kappa of block row jb - 1 placed in
+// the shadow of the MFMAs of block row jb with sched_barrier - was 3 - 11 % SLOWER than the compiler's
+// order: two workgroups per CU already overlap one wave's kappa with the other's MFMAs.)
+template <bool RBF, int KV, int NKS>
 __global__ void __launch_bounds__(256, 2)
 kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, const unsigned char* __restrict__ img2,
-                          int64_t n1, int64_t n2, int nks, float w, float scale, const float* __restrict__ nx,
+                          int64_t n1, int64_t n2, float w, float scale, const float* __restrict__ nx,
                           const float* __restrict__ ny, const float* __restrict__ V, int k, int64_t ldv,
                           int64_t tiles_per_seg, float* __restrict__ part, float* __restrict__ Y, int64_t ldy,
                           int accumulate) {
@@ -113,7 +114,8 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
     unsigned char* XB = smem;                                                  // [2][BX_IMG]
     float* VS = reinterpret_cast<float*>(smem + 2 * BX_IMG);                   // [2][BX_TJ][BX_LDV]
     float* NY = VS + 2 * BX_TJ * BX_LDV;                                       // [2][BX_TJ]
-    const float rbf_c = -0.5f * w * w * 1.4426950408889634f;
+    const float rbf_c = -0.5f * w * w * 1.4426950408889634f;  // exp(-s w^2 / 2) = exp2(rbf_c s)
+    const float m2c = -2.f * rbf_c;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -124,7 +126,7 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
     const int64_t t_hi = (t_lo + tiles_per_seg < ntile) ? t_lo + tiles_per_seg : ntile;
 
     // ---- this wave's X1 operands: 2 blocks of 16 points x 2 k-steps x 3 splits, resident ----------
-    bx_frag bh[2][2], bm[2][2], bl[2][2];
+    bx_frag bh[2][NKS], bm[2][NKS], bl[2][NKS];
     float nxr[2];
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib) {
@@ -132,36 +134,36 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
         const int r = (int)(ip & (BX_TJ - 1));
         const unsigned char* base = img1 + (ip >> 6) * BX_IMG;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bx_u4 z = {0u, 0u, 0u, 0u};
-            bx_u4 h = z, m = z, l = z;
-            if (ks < nks) {
-                const unsigned char* src = base + bx_chunk(r, 4 * ks + lq);
-                h = *reinterpret_cast<const bx_u4*>(src);
-                m = *reinterpret_cast<const bx_u4*>(src + BX_SPLIT);
-                l = *reinterpret_cast<const bx_u4*>(src + 2 * BX_SPLIT);
-            }
-            bh[ib][ks] = __builtin_bit_cast(bx_frag, h);
-            bm[ib][ks] = __builtin_bit_cast(bx_frag, m);
-            bl[ib][ks] = __builtin_bit_cast(bx_frag, l);
+        for (int ks = 0; ks < NKS; ++ks) {
+            const unsigned char* src = base + bx_chunk(r, 4 * ks + lq);
+            bh[ib][ks] = __builtin_bit_cast(bx_frag, *reinterpret_cast<const bx_u4*>(src));
+            bm[ib][ks] = __builtin_bit_cast(bx_frag, *reinterpret_cast<const bx_u4*>(src + BX_SPLIT));
+            bl[ib][ks] = __builtin_bit_cast(bx_frag, *reinterpret_cast<const bx_u4*>(src + 2 * BX_SPLIT));
         }
-        nxr[ib] = ip < n1 ? nx[ip] : 0.f;
+        // (nx has round_up(n1, 128) entries.)  RBF: the exponent is formed directly in base 2,
+        // exp2(rbf_c |x|^2 + rbf_c |y|^2 - 2 rbf_c S): the norms are kept pre-multiplied by rbf_c
+        nxr[ib] = nx[ip] * (RBF ? rbf_c : 1.f);
     }
 
     // ---- tile staging: registers -> LDS (the image is copied linearly: it is stored swizzled) -------
     bx_u4 pre[6];
     float vr[4], nyr;
+    // Every load is unconditional (a conditional load makes the compiler wait for the whole
+    // prefetch at the branch join, in front of the arithmetic): rows past n2 re-read row n2 - 1 and
+    // columns past k re-read column k - 1 - finite stand-ins that never reach the output, because the
+    // padding points carry |y'|^2 = 1e24 (kernel value exactly 0) and columns >= k are not written.
     auto load_tile = [&](int64_t t) {
         const bx_u4* src = reinterpret_cast<const bx_u4*>(img2 + t * BX_IMG);
 #pragma unroll
         for (int q = 0; q < 6; ++q) pre[q] = src[tid + 256 * q];
         const int64_t j = t * BX_TJ + (tid >> 2);
+        const float* vrow = V + (j < n2 ? j : n2 - 1) * ldv;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = (tid & 3) * 4 + u;
-            vr[u] = (j < n2 && c < k) ? V[j * ldv + c] : 0.f;
+            vr[u] = vrow[c < k ? c : k - 1];
         }
-        nyr = (tid < BX_TJ && t * BX_TJ + tid < n2) ? ny[t * BX_TJ + tid] : 0.f;
+        nyr = ny[t * BX_TJ + (tid & (BX_TJ - 1))];  // (ny has round_up(n2, 64) entries)
     };
     auto store_tile = [&](int buf) {
         bx_u4* dst = reinterpret_cast<bx_u4*>(XB + buf * BX_IMG);
@@ -169,7 +171,7 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
         for (int q = 0; q < 6; ++q) dst[tid + 256 * q] = pre[q];
         float* vs = VS + buf * BX_TJ * BX_LDV + (tid >> 2) * BX_LDV + (tid & 3) * 4;
         *reinterpret_cast<float4*>(vs) = make_float4(vr[0], vr[1], vr[2], vr[3]);
-        if (tid < BX_TJ) NY[buf * BX_TJ + tid] = nyr;
+        if (tid < BX_TJ) NY[buf * BX_TJ + tid] = nyr * (RBF ? rbf_c : 1.f);
     };
 
     // running sums, two-level (folded every BX_FOLD tiles)
@@ -184,26 +186,19 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
         for (int c = 0; c < KVN; ++c) yv[ib][c] = yvt[ib][c] = 0.f;
     }
 
-    if (t_lo < t_hi) {
-        load_tile(t_lo);
-        store_tile(0);
-        if (t_lo + 1 < t_hi) load_tile(t_lo + 1);
-    }
+    if (t_lo >= t_hi) return;  // (uniform; the launch plan never produces an empty segment)
+    const int64_t t_last = t_hi - 1;
+    load_tile(t_lo);
+    store_tile(0);
+    load_tile(t_lo + 1 < t_hi ? t_lo + 1 : t_last);
     __syncthreads();
     for (int64_t t = t_lo; t < t_hi; ++t) {
         const int buf = (int)((t - t_lo) & 1);
-        if (t + 1 < t_hi) store_tile(buf ^ 1);  // tile t + 1 (loaded one iteration ago) -> the other buffer
-        if (t + 2 < t_hi) load_tile(t + 2);     // in flight during this tile's arithmetic
-        if (((t - t_lo) & (BX_FOLD - 1)) == BX_FOLD - 1) {
-#pragma unroll
-            for (int ib = 0; ib < 2; ++ib) {
-                ytot[ib] += yacc[ib];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) yacc[ib][v] = 0.f;
-#pragma unroll
-                for (int c = 0; c < KVN; ++c) { yvt[ib][c] += yv[ib][c]; yv[ib][c] = 0.f; }
-            }
-        }
+        // tile t + 1 (loaded one iteration ago) -> the other buffer; tile t + 2 in flight during this
+        // tile's arithmetic.  Past the end the last tile is staged again (unused): no branches, the
+        // body is one basic block and the scheduler can mix matrix-core and vector work
+        store_tile(buf ^ 1);
+        load_tile(t + 2 < t_hi ? t + 2 : t_last);
         const unsigned char* xb = XB + buf * BX_IMG;
         const float* vsb = VS + buf * BX_TJ * BX_LDV;
         const float* nyb = NY + buf * BX_TJ;
@@ -217,21 +212,19 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
                 for (int v = 0; v < 4; ++v) acc[ib][v] = 0.f;
             const int r = jb * 16 + lr;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                if (ks < nks) {
-                    const unsigned char* src = xb + bx_chunk(r, 4 * ks + lq);
-                    const bx_frag ah = *reinterpret_cast<const bx_frag*>(src);
-                    const bx_frag am = *reinterpret_cast<const bx_frag*>(src + BX_SPLIT);
-                    const bx_frag al = *reinterpret_cast<const bx_frag*>(src + 2 * BX_SPLIT);
+            for (int ks = 0; ks < NKS; ++ks) {
+                const unsigned char* src = xb + bx_chunk(r, 4 * ks + lq);
+                const bx_frag ah = *reinterpret_cast<const bx_frag*>(src);
+                const bx_frag am = *reinterpret_cast<const bx_frag*>(src + BX_SPLIT);
+                const bx_frag al = *reinterpret_cast<const bx_frag*>(src + 2 * BX_SPLIT);
 #pragma unroll
-                    for (int ib = 0; ib < 2; ++ib) {  // small terms first
-                        acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ib][ks], acc[ib], 0, 0, 0);
-                        acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ib][ks], acc[ib], 0, 0, 0);
-                        acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[ib][ks], acc[ib], 0, 0, 0);
-                        acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[ib][ks], acc[ib], 0, 0, 0);
-                        acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[ib][ks], acc[ib], 0, 0, 0);
-                        acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ib][ks], acc[ib], 0, 0, 0);
-                    }
+                for (int ib = 0; ib < 2; ++ib) {  // small terms first
+                    acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ib][ks], acc[ib], 0, 0, 0);
+                    acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ib][ks], acc[ib], 0, 0, 0);
+                    acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm[ib][ks], acc[ib], 0, 0, 0);
+                    acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh[ib][ks], acc[ib], 0, 0, 0);
+                    acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[ib][ks], acc[ib], 0, 0, 0);
+                    acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ib][ks], acc[ib], 0, 0, 0);
                 }
             }
             // ---- P = kappa(|x|^2 + |y|^2 - 2 S); Y^T += V^T P^T ------------------------------------
@@ -242,9 +235,15 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
                 float p[2];
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib) {
-                    float s = nxr[ib] + nyv[v] - 2.f * acc[ib][v];
-                    s = s > 0.f ? s : 0.f;
-                    p[ib] = bx_kappa<RBF>(kind, s, w, rbf_c);
+                    if constexpr (RBF) {
+                        // add, fma, exp2 per pair (no clamp: a squared distance that rounds to
+                        // -1e-6 gives 1 + 7e-7 instead of 1)
+                        p[ib] = __builtin_amdgcn_exp2f(fmaf(acc[ib][v], m2c, nxr[ib] + nyv[v]));
+                    } else {
+                        float s = nxr[ib] + nyv[v] - 2.f * acc[ib][v];
+                        s = s > 0.f ? s : 0.f;
+                        p[ib] = kernel_value<float>(kind, s, w);
+                    }
                 }
                 const float* vj = vsb + (jb * 16 + 4 * lq + v) * BX_LDV;
                 if constexpr (KV == 0) {
@@ -266,6 +265,16 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
 #pragma unroll
                         for (int ib = 0; ib < 2; ++ib) yv[ib][c] += p[ib] * vv[c];
                 }
+            }
+        }
+        if (((t - t_lo) & (BX_FOLD - 1)) == BX_FOLD - 1) {
+#pragma unroll
+            for (int ib = 0; ib < 2; ++ib) {
+                ytot[ib] += yacc[ib];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) yacc[ib][v] = 0.f;
+#pragma unroll
+                for (int c = 0; c < KVN; ++c) { yvt[ib][c] += yv[ib][c]; yv[ib][c] = 0.f; }
             }
         }
         __syncthreads();  // tile t + 1 is in LDS; every wave is done with tile t's buffer
@@ -309,9 +318,11 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
 }
 
 // workspace behind the partial sums: affine map (2 x 64 floats), |x'|^2 of both sets, the images
+static size_t bx_float_bytes(int64_t n1, int64_t n2) {
+    return (size_t)round_up((2 * 64 + round_up(n1, BX_TI) + round_up(n2, BX_TJ)) * (int64_t)sizeof(float), 256);
+}
 size_t bx_aux_bytes(int64_t n1, int64_t n2) {
-    const size_t fl = (size_t)round_up((2 * 64 + n1 + n2) * (int64_t)sizeof(float), 256);
-    return fl + (size_t)(round_up(n1, BX_TI) / BX_TJ + round_up(n2, BX_TJ) / BX_TJ) * BX_IMG;
+    return bx_float_bytes(n1, n2) + (size_t)(round_up(n1, BX_TI) / BX_TJ + round_up(n2, BX_TJ) / BX_TJ) * BX_IMG;
 }
 
 void gram_prep_launch(const float* center, const float* ell_vec, int64_t d, float* iw, float* muw, hipStream_t st);
@@ -324,21 +335,26 @@ int launch_kmatmat_bf16x3(int kind, const float* X1, int64_t n1, int64_t ldx1, c
     float* iw = static_cast<float*>(aux);
     float* muw = iw + 64;
     float* nxp = muw + 64;
-    float* nyp = nxp + n1;
-    unsigned char* img1 = static_cast<unsigned char*>(aux) + round_up((2 * 64 + n1 + n2) * (int64_t)sizeof(float), 256);
     const int64_t n1pad = round_up(n1, BX_TI), n2pad = round_up(n2, BX_TJ);
+    float* nyp = nxp + n1pad;
+    unsigned char* img1 = static_cast<unsigned char*>(aux) + bx_float_bytes(n1, n2);
     unsigned char* img2 = img1 + (n1pad / BX_TJ) * BX_IMG;
     gram_prep_launch(center, ell_vec, d, iw, muw, st);
     hipLaunchKernelGGL(gram_split_kernel, dim3((unsigned)ceil_div(n1pad * 8, 256)), dim3(256), 0, st, X1, ldx1,
                        idx1, n1, n1pad, d, iw, muw, img1, nxp);
     hipLaunchKernelGGL(gram_split_kernel, dim3((unsigned)ceil_div(n2pad * 8, 256)), dim3(256), 0, st, X2, ldx2,
                        idx2, n2, n2pad, d, iw, muw, img2, nyp);
-    const int nks = d <= 32 ? 1 : 2;
+    const bool one_step = d <= 32;
     dim3 grid((unsigned)ceil_div(n1, BX_TI), (unsigned)S);
-#define RK_BX(RBFV, KVV)                                                                                   \
-    hipLaunchKernelGGL((kmat_matmat_bf16x3_kernel<RBFV, KVV>), grid, dim3(256), BX_SMEM_BYTES, st, kind,   \
-                       img1, img2, n1, n2, nks, w, scale, nxp, nyp, V, k, ldv, tiles_per_seg, part, Y, ldy, \
+#define RK_BX_N(RBFV, KVV, NKSV)                                                                           \
+    hipLaunchKernelGGL((kmat_matmat_bf16x3_kernel<RBFV, KVV, NKSV>), grid, dim3(256), BX_SMEM_BYTES, st,   \
+                       kind, img1, img2, n1, n2, w, scale, nxp, nyp, V, k, ldv, tiles_per_seg, part, Y, ldy, \
                        accumulate)
+#define RK_BX(RBFV, KVV)                                                                                   \
+    do {                                                                                                   \
+        if (one_step) RK_BX_N(RBFV, KVV, 1);                                                               \
+        else RK_BX_N(RBFV, KVV, 2);                                                                        \
+    } while (0)
 #define RK_BX_K(RBFV)                                                                                      \
     do {                                                                                                   \
         if (k == 1) RK_BX(RBFV, 1);                                                                        \
@@ -349,6 +365,7 @@ int launch_kmatmat_bf16x3(int kind, const float* X1, int64_t n1, int64_t ldx1, c
     if (kind == RK_RBF) RK_BX_K(true);
     else RK_BX_K(false);
 #undef RK_BX
+#undef RK_BX_N
 #undef RK_BX_K
     return launch_status("rk_kernel_matmat(bf16x3)");
 }

@@ -17,7 +17,8 @@ import torch
 
 from rlaopt_amd.ops import get_backend
 
-MODES = {"bf16x3": {}, "mfma32": {"RK_KMAT_BF16X3": "0"}, "direct": {"RK_KMAT_MFMA": "0"}}
+MODES = {"bf16x3": {}, "mfma32": {"RK_KMAT_BF16X3": "0"},
+         "direct": {"RK_KMAT_MFMA": "0"}}
 
 
 def set_mode(mode):
