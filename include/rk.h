@@ -134,6 +134,26 @@ int rk_symm_matmat(int dtype, int store_dtype, const void* Kp, int64_t n, int64_
                    void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * SAP step size  [a12]
+ *
+ * lambda_max(Pinv (K + reg I)) by power iteration with the stopping rule of
+ * rlaopt/spectral_estimators/spectral_norm.py:11-29 (|sig_new - sig| <= rtol * sig, at most
+ * max_iters steps), the whole loop queued on `stream` with NO host synchronisation: the
+ * stopping test is evaluated on the device and freezes the state, so what is left in
+ * state[0] is the value the reference returns.  K: the materialised block oracle K(X[blk],
+ * X[blk]) (m x m, ldk; rlaopt/solvers/sap.py:89-111).  Pinv x = (x - U (M (U^T x))) / rho with
+ * the Nystrom factors U (m x r) and M (r x r float64 row-major, or - mdiag != 0 - a length-r
+ * float64 diagonal); U == NULL: Pinv = identity (rho must be 1).  v: start vector in, last
+ * iterate out.  state: device float64[3] = {eigenvalue estimate, converged flag, iterations}.
+ * Replaces ~10 launches and 2 host read-backs per iteration of the reference-shaped loop.
+ * ---------------------------------------------------------------------------------- */
+size_t rk_power_iteration_ws_bytes(int dtype, int64_t m, int64_t r);
+int rk_power_iteration(int dtype, const void* K, int64_t m, int64_t ldk, double reg,
+                       const void* U, int64_t r, int64_t ldu, const double* M, int mdiag,
+                       double rho, void* v, int64_t max_iters, double rtol, double* state,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * HBM-streaming skinny products  [a3 cached shard product, a6 dense tensor operator,
  * a9 Nystrom apply, a11 block dots]
  * ---------------------------------------------------------------------------------- */

@@ -823,12 +823,186 @@ static int matmat_skinny_t_impl(const T* A, int64_t m, int64_t n, int64_t lda, c
     return launch_status("rk_matmat_skinny_t(finish)");
 }
 
+// ------------------------------------------------------------------------------------------
+// power iteration for the SAP step size: lambda_max(Pinv (K + reg I)), device-resident
+// ------------------------------------------------------------------------------------------
+// t = M c for the r x r float64 apply factor of the Nystrom inverse (or its diagonal form), cast to T
+template <typename T>
+__global__ void __launch_bounds__(256)
+pi_factor_kernel(const double* __restrict__ M, int mdiag, const double* __restrict__ c, int r,
+                 T* __restrict__ t) {
+    for (int i = threadIdx.x; i < r; i += 256) {
+        double s = 0.0;
+        if (mdiag) {
+            s = M[i] * c[i];
+        } else {
+            const double* row = M + (int64_t)i * r;
+            for (int j = 0; j < r; ++j) s += row[j] * c[j];
+        }
+        t[i] = (T)s;
+    }
+}
+
+// block-wide sum of a double (1024 threads), result in every thread
+__device__ __forceinline__ double pi_block_sum(double x, double* red) {
+    x = wave_total_lane63(x);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();  // (red may still be read from a previous call)
+    if (lane == 63) red[wave] = x;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[w];
+    return s;
+}
+
+// v <- v / |v|, state <- {sig = 0, done = 0, iterations = 0}
+template <typename T>
+__global__ void __launch_bounds__(1024)
+pi_start_kernel(T* __restrict__ v, int64_t m, double* __restrict__ state) {
+    __shared__ double red[16];
+    double ss = 0.0;
+    for (int64_t i = threadIdx.x; i < m; i += 1024) ss += (double)v[i] * (double)v[i];
+    const double nrm = sqrt(pi_block_sum(ss, red));
+    const T inv = (T)(1.0 / nrm);
+    for (int64_t i = threadIdx.x; i < m; i += 1024) v[i] *= inv;
+    if (threadIdx.x == 0) { state[0] = 0.0; state[1] = 0.0; state[2] = 0.0; }
+}
+
+// One step of rlaopt/spectral_estimators/spectral_norm.py:22-29 with z = S v already formed:
+//     sig_new = v . z;  v = z / |z|;  err = |sig_new - sig|;  sig = sig_new;  i += 1
+// and the loop test "i < max_iters and err > rtol * sig" evaluated on the device: once it fails the
+// state is frozen (later launches of this kernel leave sig and the count alone), so the value left
+// in state[0] is the reference's return value although the host never looks at the iteration.
+// Inner products accumulate in float64 and are rounded to the working type like torch.dot's result.
+template <typename T>
+__global__ void __launch_bounds__(1024)
+pi_update_kernel(T* __restrict__ v, const T* __restrict__ z, int64_t m, double rtol,
+                 double* __restrict__ state) {
+    __shared__ double red[16];
+    double dot = 0.0, ss = 0.0;
+    for (int64_t i = threadIdx.x; i < m; i += 1024) {
+        const double zi = (double)z[i];
+        dot += (double)v[i] * zi;
+        ss += zi * zi;
+    }
+    dot = pi_block_sum(dot, red);
+    ss = pi_block_sum(ss, red);
+    const T inv = (T)(1.0 / (double)(T)sqrt(ss));
+    for (int64_t i = threadIdx.x; i < m; i += 1024) v[i] = z[i] * inv;
+    if (threadIdx.x == 0 && state[1] == 0.0) {
+        const double sig_new = (double)(T)dot;
+        const double err = fabs(sig_new - state[0]);
+        state[0] = sig_new;
+        state[2] += 1.0;
+        if (!(err > rtol * sig_new)) state[1] = 1.0;
+    }
+}
+
+struct PIPlan {
+    size_t off_y, off_z, off_t, off_c, off_nn, nn_bytes, off_tt, tt_bytes, total;
+};
+
+static PIPlan plan_pi(int dtype, int64_t m, int64_t r) {
+    const size_t es = dtype == RK_F32 ? 4 : 8;
+    PIPlan p;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += round_up((int64_t)bytes, 256); return at; };
+    p.off_y = take(m * es);
+    p.off_z = take(m * es);
+    p.off_t = take((r > 0 ? r : 1) * es);
+    p.off_c = take((r > 0 ? r : 1) * sizeof(double));
+    const NNPlan a = plan_nn(dtype, m, m, 1);
+    size_t nn = a.S > 1 ? (size_t)a.S * m * es : 0;
+    if (r > 0) {
+        const NNPlan b = plan_nn(dtype, m, r, 1);
+        const size_t nb = b.S > 1 ? (size_t)b.S * m * es : 0;
+        if (nb > nn) nn = nb;
+    }
+    p.nn_bytes = nn;
+    p.off_nn = take(nn ? nn : 1);
+    p.tt_bytes = r > 0 ? (size_t)plan_t(dtype, m, r).S * r * es : 0;
+    p.off_tt = take(p.tt_bytes ? p.tt_bytes : 1);
+    p.total = o;
+    return p;
+}
+
+template <typename T>
+static int power_iteration_impl(int dtype, const T* K, int64_t m, int64_t ldk, double reg, const T* U,
+                                int64_t r, int64_t ldu, const double* M, int mdiag, double rho, T* v,
+                                int64_t max_iters, double rtol, double* state, void* ws, hipStream_t st) {
+    const PIPlan p = plan_pi(dtype, m, r);
+    char* base = static_cast<char*>(ws);
+    T* y = reinterpret_cast<T*>(base + p.off_y);
+    T* z = reinterpret_cast<T*>(base + p.off_z);
+    T* t = reinterpret_cast<T*>(base + p.off_t);
+    double* c = reinterpret_cast<double*>(base + p.off_c);
+    void* nn_ws = p.nn_bytes ? base + p.off_nn : nullptr;
+    void* tt_ws = base + p.off_tt;
+    hipLaunchKernelGGL((pi_start_kernel<T>), dim3(1), dim3(1024), 0, st, v, m, state);
+    int rc = launch_status("rk_power_iteration(start)");
+    const double inv_rho = 1.0 / rho;
+    for (int64_t it = 0; it < max_iters && rc == RK_OK; ++it) {
+        // y = K v + reg v
+        rc = matmat_skinny_impl<T>(K, m, m, ldk, v, 1, 1, 1.0, 0.0, nullptr, 1, reg, 0, y, 1, nn_ws,
+                                   p.nn_bytes, st, dtype);
+        if (rc != RK_OK) break;
+        const T* zin = y;
+        if (U != nullptr) {
+            // z = (y - U (M (U^T y))) / rho
+            rc = matmat_skinny_t_impl<T>(U, m, r, ldu, y, 1, 1, 1.0, 0.0, nullptr, 1, c, 1, 1, tt_ws,
+                                         p.tt_bytes, st, dtype);
+            if (rc != RK_OK) break;
+            hipLaunchKernelGGL((pi_factor_kernel<T>), dim3(1), dim3(256), 0, st, M, mdiag, c, (int)r, t);
+            rc = matmat_skinny_impl<T>(U, m, r, ldu, t, 1, 1, -inv_rho, inv_rho, y, 1, 0.0, 0, z, 1, nn_ws,
+                                       p.nn_bytes, st, dtype);
+            if (rc != RK_OK) break;
+            zin = z;
+        } else if (rho != 1.0) {
+            set_error("rk_power_iteration: without U the preconditioner is the identity (rho must be 1)");
+            return RK_ERR_INVALID;
+        }
+        hipLaunchKernelGGL((pi_update_kernel<T>), dim3(1), dim3(1024), 0, st, v, zin, m, rtol, state);
+        rc = launch_status("rk_power_iteration(update)");
+    }
+    return rc;
+}
+
 }  // namespace rk
 
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
 using namespace rk;
+
+extern "C" size_t rk_power_iteration_ws_bytes(int dtype, int64_t m, int64_t r) {
+    if (m <= 0 || r < 0) return 0;
+    return plan_pi(dtype, m, r).total;
+}
+
+extern "C" int rk_power_iteration(int dtype, const void* K, int64_t m, int64_t ldk, double reg,
+                                  const void* U, int64_t r, int64_t ldu, const double* M, int mdiag,
+                                  double rho, void* v, int64_t max_iters, double rtol, double* state,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    clear_error();
+    RK_REQUIRE(dtype == RK_F32 || dtype == RK_F64, "rk_power_iteration: bad dtype %d", dtype);
+    RK_REQUIRE(K && v && state, "rk_power_iteration: null pointer");
+    RK_REQUIRE(m > 0 && ldk >= m && max_iters >= 0 && max_iters <= 1000, "rk_power_iteration: bad sizes");
+    RK_REQUIRE(U == nullptr || (r > 0 && r <= 4096 && ldu >= r && M != nullptr && rho > 0.0),
+               "rk_power_iteration: bad preconditioner factors");
+    const int64_t rr = U ? r : 0;
+    const size_t need = plan_pi(dtype, m, rr).total;
+    if (ws == nullptr || ws_bytes < need) {
+        set_error("rk_power_iteration: workspace %zu B < required %zu B", ws_bytes, need);
+        return RK_ERR_WORKSPACE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == RK_F32)
+        return power_iteration_impl<float>(dtype, (const float*)K, m, ldk, reg, (const float*)U, rr, ldu, M,
+                                           mdiag, rho, (float*)v, max_iters, rtol, state, ws, st);
+    return power_iteration_impl<double>(dtype, (const double*)K, m, ldk, reg, (const double*)U, rr, ldu, M,
+                                        mdiag, rho, (double*)v, max_iters, rtol, state, ws, st);
+}
 
 extern "C" size_t rk_matmat_skinny_ws_bytes(int dtype, int64_t m, int64_t n, int64_t k) {
     if (m <= 0 || n <= 0 || k <= 0 || k > 16) return 0;

@@ -600,6 +600,7 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
         parts = len(self._shard_devices)
         bounds = _dist.row_chunks(blk.shape[0], parts)
         ops = []
+        dense = [None] * len(bounds)
         for i, (lo, hi) in enumerate(bounds):
             dev = self._shard_devices[i]
             shape = torch.Size((hi - lo, blk.shape[0]))
@@ -614,6 +615,7 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
                 # later product streams it: one SAP step multiplies with K_bb ~17 times (7 sketch
                 # passes of 16 columns, <= 10 power iterations) - measured 2 ms of a 17 ms step
                 Kb = be.kernel_materialize(self._kind, A1c, A2b, cfg.lengthscale, scale=self._scaling)
+                dense[i] = Kb
 
                 def matvec(x, Kb=Kb):
                     return be.matmat(Kb, x)
@@ -625,10 +627,13 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
                                             gram_center=gc)
 
             ops.append(LinOp(device=dev, shape=shape, matvec=matvec, matmat=matvec, dtype=self.dtype))
-        return _DistributedLinOp(
+        op = _DistributedLinOp(
             shape=torch.Size((blk.shape[0], blk.shape[0])), A=ops, distribution_mode="row",
             is_new=False, group=self._group, spmd=self._spmd,
         )
+        if len(bounds) == 1 and dense[0] is not None:
+            op._rk_dense = dense[0]  # the whole block as one resident tensor (fused SAP step size)
+        return op
 
     def shutdown(self):
         """Release the materialised shards (base.py:507-520)."""

@@ -473,6 +473,36 @@ class HipBackend:
         _lib.check(rc, "rk_normal_pass")
         return G, ss
 
+    def power_iteration(self, K, reg, v0, U=None, M=None, rho=1.0, max_iters=10, rtol=1e-3):
+        """lambda_max(Pinv (K + reg I)) by the reference's power iteration
+        (spectral_estimators/spectral_norm.py:11-29), queued as one launch sequence without host
+        synchronisation (``rk_power_iteration``).  Pinv = (I - U M U^T) / rho for Nystrom factors
+        (M: r x r float64, or a length-r float64 diagonal), the identity when U is None.  Returns a
+        float64 device tensor [eigenvalue, converged, iterations]; ``v0`` is overwritten."""
+        dev = _req(K, v0, U, M)
+        K, ldk = _rowmajor(K)
+        m = K.shape[0]
+        if K.shape[1] != m or v0.shape != (m,) or v0.dtype != K.dtype or not v0.is_contiguous():
+            raise ValueError("power_iteration: K must be square and v0 a contiguous vector of its dtype")
+        r, ldu, mdiag = 0, 1, 0
+        if U is not None:
+            U, ldu = _rowmajor(U)
+            r = U.shape[1]
+            if U.shape[0] != m or U.dtype != K.dtype or M is None or M.dtype != torch.float64:
+                raise ValueError("power_iteration: U must be m x r in K's dtype and M float64")
+            M = M.contiguous()
+            mdiag = int(M.ndim == 1)
+            if tuple(M.shape) not in ((r,), (r, r)):
+                raise ValueError("power_iteration: M must be r x r or length r")
+        state = torch.empty(3, dtype=torch.float64, device=dev)
+        ws, wsn = self._workspace(dev, self._lib.rk_power_iteration_ws_bytes(_dt(K), m, r))
+        rc = self._lib.rk_power_iteration(
+            _dt(K), _ptr(K), m, ldk, float(reg), _ptr(U), r, ldu, _ptr(M), mdiag, float(rho), _ptr(v0),
+            int(max_iters), float(rtol), _ptr(state), _ptr(ws), wsn, _stream(dev),
+        )
+        _lib.check(rc, "rk_power_iteration")
+        return state
+
     def small_solve(self, A, B):
         """float64 device solve A X = B, A (k x k), B (k x nrhs), k, nrhs <= 16."""
         dev = _req(A, B)
@@ -552,7 +582,7 @@ def _guard_device(fn):
 
 for _name in ("gram_center", "kernel_materialize", "kernel_matmat", "sympack_materialize", "symm_matmat",
               "matmat", "rmatmat", "gemm", "gram_tn", "pcg_update_wr", "pcg_update_p", "axpby_cols",
-              "normal_pass", "small_solve", "sparse_sign_apply", "randn"):
+              "normal_pass", "small_solve", "sparse_sign_apply", "randn", "power_iteration"):
     setattr(HipBackend, _name, _guard_device(getattr(HipBackend, _name)))
 del _name
 

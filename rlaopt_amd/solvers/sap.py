@@ -74,9 +74,9 @@ class SAP(Solver):
         self._blocks = iter(blocks) if blocks is not None else None
         self._starts = iter(starts) if starts is not None else None
 
-    def _get_precond(self, blk: torch.Tensor) -> Preconditioner:
+    def _get_precond(self, blk: torch.Tensor, K_bb=None) -> Preconditioner:
         P = _pf_get_precond(self.precond_config)
-        P._update(self.system.A_blk_oracle(blk), self.device)
+        P._update(self.system.A_blk_oracle(blk) if K_bb is None else K_bb, self.device)
         P._update_damping(baseline_rho=self.system.reg)
         return P
 
@@ -94,20 +94,60 @@ class SAP(Solver):
         gen.manual_seed(seed)
         return torch.randperm(n, device=self._W.device, generator=gen)[: self.blk_sz]
 
-    def _get_stepsize(self, blk: torch.Tensor, blk_precond: Preconditioner) -> float:
+    def _fused_stepsize(self, K_bb, blk_precond, v0):
+        """1 / lambda_max on the device, no host synchronisation (``rk_power_iteration``): needs the
+        block oracle as one resident tensor and a preconditioner whose inverse is I or
+        (I - U M U^T) / rho.  Returns a 0-dim tensor, or None when this layout does not apply."""
+        from ..ops import get_backend
+        from ..preconditioners.identity import Identity
+        from ..preconditioners.nystrom import Nystrom
+
+        be = get_backend()
+        dense = getattr(K_bb, "_rk_dense", None)
+        if (dense is None or not hasattr(be, "power_iteration") or not dense.is_cuda
+                or os.environ.get("RK_SAP_FUSED_POWER", "1") == "0"):
+            return None
+        dt = self._W.dtype
+        if v0 is None:
+            from ..sketches import _device_randn  # the draw randomized_powering would make
+
+            v0 = _device_randn(self.blk_sz, 1, dt, dense.device)[:, 0]
+        v0 = v0.to(device=dense.device, dtype=dt).contiguous().clone()
+        if isinstance(blk_precond, Nystrom) and not blk_precond._sharded:
+            state = be.power_iteration(dense, self.system.reg, v0, U=blk_precond.U,
+                                       M=blk_precond._apply_factor(), rho=float(blk_precond.config.rho),
+                                       max_iters=self.power_iters, rtol=1e-3)
+        elif isinstance(blk_precond, Identity):
+            state = be.power_iteration(dense, self.system.reg, v0, max_iters=self.power_iters, rtol=1e-3)
+        else:
+            return None
+        return state[0].reciprocal().to(dt)
+
+    def _get_stepsize(self, blk: torch.Tensor, blk_precond: Preconditioner, K_bb=None):
         if isinstance(self.precond_config, NewtonConfig) and self.precond_config.rho == self.system.reg:
             return 1.0  # exact block solve
-        K_bb = self.system.A_blk_oracle(blk)
+        if K_bb is None:
+            K_bb = self.system.A_blk_oracle(blk)
         reg = self.system.reg
+        v0 = next(self._starts).to(device=self.device, dtype=self._W.dtype) if self._starts else None
+        eta = self._fused_stepsize(K_bb, blk_precond, v0)
+        if eta is not None:
+            return eta
         S = LinOp(
             device=self.device,
             shape=torch.Size((self.blk_sz, self.blk_sz)),
             matvec=blk_precond._inverse_matmul_compose(lambda v: K_bb @ v + reg * v),
             dtype=self._W.dtype,
         )
-        v0 = next(self._starts).to(device=self.device, dtype=self._W.dtype) if self._starts else None
         max_eig, _ = randomized_powering(S, max_iters=self.power_iters, v0=v0)
         return float(max_eig) ** -1.0
+
+    def _precond_and_stepsize(self, blk):
+        """Block preconditioner and step size from ONE evaluation of the block oracle (the
+        reference builds K(X[blk], X[blk]) twice per step, sap.py:64-66 and :95)."""
+        K_bb = self.system.A_blk_oracle(blk)
+        blk_precond = self._get_precond(blk, K_bb)
+        return blk_precond, self._get_stepsize(blk, blk_precond, K_bb)
 
     def _side_stream(self):
         """Second HIP stream for the block gradient (single-process GPU runs only: in an SPMD run
@@ -163,17 +203,16 @@ class SAP(Solver):
             if hi is not None:  # the latency-bound chain on a high-priority stream
                 hi.wait_stream(main)
                 with torch.cuda.stream(hi):
-                    blk_precond = self._get_precond(blk)
-                    eta = self._get_stepsize(blk, blk_precond)
+                    blk_precond, eta = self._precond_and_stepsize(blk)
                 main.wait_stream(hi)
             else:
-                blk_precond = self._get_precond(blk)
-                eta = self._get_stepsize(blk, blk_precond)
+                blk_precond, eta = self._precond_and_stepsize(blk)
             main.wait_stream(side)
             grad.record_stream(main)
+            if isinstance(eta, torch.Tensor):
+                eta.record_stream(main)
         else:
-            blk_precond = self._get_precond(blk)
-            eta = self._get_stepsize(blk, blk_precond)
+            blk_precond, eta = self._precond_and_stepsize(blk)
             grad = self._block_gradient(loc, self.system.B[:, cols], blk_d)
         d = blk_precond._inv @ grad
         if not self.accel:

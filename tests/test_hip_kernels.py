@@ -461,3 +461,53 @@ def test_gram_center_and_bound_values(be):
         torch.cuda.synchronize()
         torch.testing.assert_close(center.double().cpu(), mean.cpu(), rtol=1e-5, atol=1e-6)
         assert abs(float(bound) - bound_ref) <= 1e-4 * bound_ref
+
+
+@pytest.mark.parametrize("precond", ["nystrom_dense", "nystrom_diag", "identity"])
+def test_power_iteration_matches_the_reference_loop(be, prec, precond):
+    """rk_power_iteration (whole loop on the device, stopping rule frozen in device state) against
+    the reference-shaped host loop (spectral_estimators/spectral_norm.py:11-29) on the same operator
+    Pinv (K + reg I): same eigenvalue estimate, same number of iterations."""
+    from rlaopt_amd.linops import LinOp
+    from rlaopt_amd.spectral_estimators import randomized_powering
+
+    dt = DTYPES[prec]
+    gen = torch.Generator().manual_seed(17)
+    m, r, d = 700, 24, 5
+    X = torch.randn(m, d, dtype=torch.float64, generator=gen) / d**0.5
+    K = torch.exp(-0.5 * torch.cdist(X, X) ** 2).to(dt).to(dev())
+    U = torch.linalg.qr(torch.randn(m, r, dtype=torch.float64, generator=gen)).Q.to(dt).to(dev())
+    reg, rho = 1e-2, 0.3
+    v0 = torch.randn(m, dtype=torch.float64, generator=gen).to(dt).to(dev())
+    if precond == "nystrom_dense":
+        A = torch.randn(r, r, dtype=torch.float64, generator=gen)
+        M = (torch.linalg.inv(A @ A.T + r * torch.eye(r, dtype=torch.float64)) * r * 0.7).to(dev())
+    elif precond == "nystrom_diag":
+        M = torch.rand(r, dtype=torch.float64, generator=gen).to(dev())
+    else:
+        M, U, rho = None, None, 1.0
+
+    def pinv(y):
+        if U is None:
+            return y
+        t = U.T.double() @ y.double()
+        t = M @ t if M.ndim == 2 else M * t
+        return ((y.double() - U.double() @ t) / rho).to(dt)
+
+    S = LinOp(device=dev(), shape=torch.Size((m, m)), matvec=lambda v: pinv(K @ v + reg * v), dtype=dt)
+    for max_iters, rtol in ((10, 1e-3), (3, 1e-3), (40, 1e-7)):
+        want, _ = randomized_powering(S, max_iters=max_iters, rtol=rtol, v0=v0.clone())
+        # iterations the reference loop used
+        v, sig, its, err = v0 / v0.norm(), 0.0, 0, float("inf")
+        while its < max_iters and err > rtol * sig:
+            z = S @ v
+            s_new = float(torch.dot(v, z))
+            v = z / z.norm()
+            err, sig, its = abs(s_new - sig), s_new, its + 1
+        state = be.power_iteration(K, reg, v0.clone(), U=U, M=M, rho=rho, max_iters=max_iters, rtol=rtol)
+        got, done, used = (float(x) for x in state)
+        tol = 2e-5 if dt == torch.float32 else 1e-11
+        assert abs(got - float(want)) <= tol * abs(float(want)), (precond, max_iters, got, float(want))
+        if rtol > 1e-6:  # (at rtol 1e-7 the float32 stopping decision is within rounding of the threshold)
+            assert int(used) == its, (precond, max_iters, used, its)
+            assert bool(done) == (err <= rtol * sig)
