@@ -768,7 +768,9 @@ static TPlan plan_t(int dtype, int64_t m, int64_t n) {
     TPlan p;
     p.ncc = ceil_div(n, step);
     int64_t S = ceil_div(16384, p.ncc);  // ~16k waves (4 rounds of the resident set)
-    const int64_t max_S = ceil_div(m, 256);  // >= 256 rows per wave
+    // >= 256 rows per wave; a short operand (the 5 000 x 100 Nystrom factor of a SAP block: 20 waves
+    // at 256 rows, 37 us) is cut finer - it is latency-, not bandwidth-bound
+    const int64_t max_S = (m >= 2048 && m < 65536) ? ceil_div(m, 32) : ceil_div(m, 256);
     if (S > max_S) S = max_S;
     if (S < 1) S = 1;
     p.seg_rows = ceil_div(m, S);
@@ -827,19 +829,25 @@ static int matmat_skinny_t_impl(const T* A, int64_t m, int64_t n, int64_t lda, c
 // power iteration for the SAP step size: lambda_max(Pinv (K + reg I)), device-resident
 // ------------------------------------------------------------------------------------------
 // t = M c for the r x r float64 apply factor of the Nystrom inverse (or its diagonal form), cast to T
+// (16 lanes per row of M, columns strided over them: coalesced 128-byte runs, 64 rows per pass)
 template <typename T>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 pi_factor_kernel(const double* __restrict__ M, int mdiag, const double* __restrict__ c, int r,
                  T* __restrict__ t) {
-    for (int i = threadIdx.x; i < r; i += 256) {
+    if (mdiag) {
+        for (int i = threadIdx.x; i < r; i += 1024) t[i] = (T)(M[i] * c[i]);
+        return;
+    }
+    const int l = threadIdx.x & 15;
+    for (int i = threadIdx.x >> 4; i < r; i += 64) {  // (uniform trip count within a 16-lane row)
+        const double* row = M + (int64_t)i * r;
         double s = 0.0;
-        if (mdiag) {
-            s = M[i] * c[i];
-        } else {
-            const double* row = M + (int64_t)i * r;
-            for (int j = 0; j < r; ++j) s += row[j] * c[j];
-        }
-        t[i] = (T)s;
+        for (int j = l; j < r; j += 16) s += row[j] * c[j];
+        s += dpp_fetch<0xB1, 0xF>(s);
+        s += dpp_fetch<0x4E, 0xF>(s);
+        s += dpp_fetch<0x141, 0xF>(s);
+        s += dpp_fetch<0x140, 0xF>(s);
+        if (l == 0) t[i] = (T)s;
     }
 }
 
@@ -953,7 +961,7 @@ static int power_iteration_impl(int dtype, const T* K, int64_t m, int64_t ldk, d
             rc = matmat_skinny_t_impl<T>(U, m, r, ldu, y, 1, 1, 1.0, 0.0, nullptr, 1, c, 1, 1, tt_ws,
                                          p.tt_bytes, st, dtype);
             if (rc != RK_OK) break;
-            hipLaunchKernelGGL((pi_factor_kernel<T>), dim3(1), dim3(256), 0, st, M, mdiag, c, (int)r, t);
+            hipLaunchKernelGGL((pi_factor_kernel<T>), dim3(1), dim3(1024), 0, st, M, mdiag, c, (int)r, t);
             rc = matmat_skinny_impl<T>(U, m, r, ldu, t, 1, 1, -inv_rho, inv_rho, y, 1, 0.0, 0, z, 1, nn_ws,
                                        p.nn_bytes, st, dtype);
             if (rc != RK_OK) break;

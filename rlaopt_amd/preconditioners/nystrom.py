@@ -65,7 +65,11 @@ class Nystrom(Preconditioner):
         self._group = None
 
     # -- assembly ------------------------------------------------------------------------------
-    def _update(self, A, device):
+    def _update(self, A, device, before_host_wait=None):
+        """``before_host_wait``: called once, right before the first device -> host read-back (the
+        r x r Gram blocks), i.e. when everything this assembly can do without the host has been
+        queued: a caller with independent device work (SAP's block gradient) launches it there, so
+        that it runs while the host factorises instead of delaying the kernels queued so far."""
         be = get_backend()
         if A.dtype != torch.float64:
             self.low_precision = True
@@ -84,6 +88,8 @@ class Nystrom(Preconditioner):
         both = torch.stack([be.gram_tn(Om_rows, Y), be.gram_tn(Y, Y)])  # float64 (2, r, r)
         if self._sharded:
             _dist.all_reduce_sum(both, self._group)
+        if before_host_wait is not None:
+            before_host_wait()
         core, gram = both.cpu()
 
         shift = torch.finfo(A.dtype).eps * torch.trace(core)  # eps of the WORKING dtype

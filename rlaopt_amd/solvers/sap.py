@@ -74,9 +74,13 @@ class SAP(Solver):
         self._blocks = iter(blocks) if blocks is not None else None
         self._starts = iter(starts) if starts is not None else None
 
-    def _get_precond(self, blk: torch.Tensor, K_bb=None) -> Preconditioner:
+    def _get_precond(self, blk: torch.Tensor, K_bb=None, before_host_wait=None) -> Preconditioner:
         P = _pf_get_precond(self.precond_config)
-        P._update(self.system.A_blk_oracle(blk) if K_bb is None else K_bb, self.device)
+        K_bb = self.system.A_blk_oracle(blk) if K_bb is None else K_bb
+        if before_host_wait is not None and isinstance(self.precond_config, NystromConfig):
+            P._update(K_bb, self.device, before_host_wait=before_host_wait)
+        else:
+            P._update(K_bb, self.device)
         P._update_damping(baseline_rho=self.system.reg)
         return P
 
@@ -142,11 +146,11 @@ class SAP(Solver):
         max_eig, _ = randomized_powering(S, max_iters=self.power_iters, v0=v0)
         return float(max_eig) ** -1.0
 
-    def _precond_and_stepsize(self, blk):
+    def _precond_and_stepsize(self, blk, before_host_wait=None):
         """Block preconditioner and step size from ONE evaluation of the block oracle (the
         reference builds K(X[blk], X[blk]) twice per step, sap.py:64-66 and :95)."""
         K_bb = self.system.A_blk_oracle(blk)
-        blk_precond = self._get_precond(blk, K_bb)
+        blk_precond = self._get_precond(blk, K_bb, before_host_wait)
         return blk_precond, self._get_stepsize(blk, blk_precond, K_bb)
 
     def _side_stream(self):
@@ -188,25 +192,35 @@ class SAP(Solver):
         blk_d = blk.to(self._W.device)
         base = self.Y if self.accel else self._W
         loc = base[:, cols]
-        # The block gradient (the blk x n row-oracle product: 2/3 of the iteration) depends on
-        # neither the block preconditioner nor the step size.  On a GPU it is queued first, on a
-        # side stream, so that it overlaps the preconditioner assembly and the power iteration -
-        # both full of small launches and host round trips (r x r eigh, convergence tests) that
-        # would otherwise leave the device idle in front of it.
         side = self._side_stream()
         if side is not None:
+            # The block gradient (the blk x n row-oracle product: the largest kernel of the step)
+            # depends on neither the block preconditioner nor the step size; it runs on a side stream
+            # while the host factorises the r x r blocks of the preconditioner.  It is queued at the
+            # assembly's first host wait rather than up front: kernels of the latency-bound chain that
+            # share the device with it run ~4x slower, so the chain's device-only head goes first.
             main = torch.cuda.current_stream(self._W.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                grad = self._block_gradient(loc, self.system.B[:, cols], blk_d)
+            box = {}
+
+            def launch_grad():
+                if "grad" not in box:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        box["grad"] = self._block_gradient(loc, self.system.B[:, cols], blk_d)
+
+            early = os.environ.get("RK_SAP_GRAD_FIRST", "0") == "1"
+            if early:
+                launch_grad()
             hi = self._chain_stream()
             if hi is not None:  # the latency-bound chain on a high-priority stream
                 hi.wait_stream(main)
                 with torch.cuda.stream(hi):
-                    blk_precond, eta = self._precond_and_stepsize(blk)
+                    blk_precond, eta = self._precond_and_stepsize(blk, launch_grad)
                 main.wait_stream(hi)
             else:
-                blk_precond, eta = self._precond_and_stepsize(blk)
+                blk_precond, eta = self._precond_and_stepsize(blk, launch_grad)
+            launch_grad()  # (preconditioners that never wait on the host)
+            grad = box["grad"]
             main.wait_stream(side)
             grad.record_stream(main)
             if isinstance(eta, torch.Tensor):
