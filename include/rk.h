@@ -147,6 +147,18 @@ int rk_symm_matmat(int dtype, int store_dtype, const void* Kp, int64_t n, int64_
  * iterate out.  state: device float64[3] = {eigenvalue estimate, converged flag, iterations}.
  * Replaces ~10 launches and 2 host read-backs per iteration of the reference-shaped loop.
  * ---------------------------------------------------------------------------------- */
+/* SAP / ASkotch iterate update (rlaopt/solvers/sap.py:139-175) on contiguous n x k iterates
+ * (ld == k), two launches instead of a dozen element-wise / index_put kernels:
+ *   accel != 0:  W <- Y;  V <- beta V + (1 - beta) Y;  on the rows blk[0 .. nb) (distinct):
+ *                W -= eta D, V -= (eta gamma) D;  then Y <- alpha V + (1 - alpha) W everywhere
+ *   accel == 0:  W[blk] -= eta D
+ * D: nb x k block update (Pinv applied to the block gradient).  eta: `eta_dev` (ONE device
+ * element of `dtype`, e.g. 1 / state[0] of rk_power_iteration - no host read-back) or, when
+ * eta_dev is NULL, the host value `eta_host`. */
+int rk_sap_update(int dtype, int64_t n, int64_t k, void* W, void* V, void* Y, int64_t ld,
+                  const int64_t* blk, int64_t nb, const void* D, int64_t ldd,
+                  const void* eta_dev, double eta_host, int accel, double beta, double gamma,
+                  double alpha, void* stream);
 size_t rk_power_iteration_ws_bytes(int dtype, int64_t m, int64_t r);
 int rk_power_iteration(int dtype, const void* K, int64_t m, int64_t ldk, double reg,
                        const void* U, int64_t r, int64_t ldu, const double* M, int mdiag,

@@ -826,6 +826,44 @@ static int matmat_skinny_t_impl(const T* A, int64_t m, int64_t n, int64_t lda, c
 }
 
 // ------------------------------------------------------------------------------------------
+// SAP / ASkotch iterate update (rlaopt/solvers/sap.py:139-175) in two launches
+// ------------------------------------------------------------------------------------------
+// every row: W <- Y;  V <- beta V + (1 - beta) Y;  Y <- alpha V + (1 - alpha) W
+template <typename T>
+__global__ void __launch_bounds__(256)
+sap_dense_kernel(int64_t total, T* __restrict__ W, T* __restrict__ V, T* __restrict__ Y, T beta, T alpha) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const T y = Y[e];
+    const T v = beta * V[e] + (T(1) - beta) * y;
+    W[e] = y;
+    V[e] = v;
+    Y[e] = alpha * v + (T(1) - alpha) * y;
+}
+
+// rows of the block (distinct): W -= eta d;  V -= (eta gamma) d;  Y <- alpha V + (1 - alpha) W
+template <typename T>
+__global__ void __launch_bounds__(256)
+sap_block_kernel(int64_t nb, int k, const int64_t* __restrict__ blk, const T* __restrict__ D, int64_t ldd,
+                 const T* __restrict__ eta_dev, T eta_host, T* __restrict__ W, T* __restrict__ V,
+                 T* __restrict__ Y, int64_t ld, int accel, T gamma, T alpha) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nb * k) return;
+    const int64_t p = e / k;
+    const int c = (int)(e - p * k);
+    const T eta = eta_dev ? eta_dev[0] : eta_host;
+    const T d = D[p * ldd + c];
+    const int64_t at = blk[p] * ld + c;
+    const T w = W[at] - eta * d;
+    W[at] = w;
+    if (accel) {
+        const T v = V[at] - (eta * gamma) * d;
+        V[at] = v;
+        Y[at] = alpha * v + (T(1) - alpha) * w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // power iteration for the SAP step size: lambda_max(Pinv (K + reg I)), device-resident
 // ------------------------------------------------------------------------------------------
 // t = M c for the r x r float64 apply factor of the Nystrom inverse (or its diagonal form), cast to T
@@ -982,6 +1020,36 @@ static int power_iteration_impl(int dtype, const T* K, int64_t m, int64_t ldk, d
 // C ABI
 // ------------------------------------------------------------------------------------------
 using namespace rk;
+
+extern "C" int rk_sap_update(int dtype, int64_t n, int64_t k, void* W, void* V, void* Y, int64_t ld,
+                             const int64_t* blk, int64_t nb, const void* D, int64_t ldd,
+                             const void* eta_dev, double eta_host, int accel, double beta, double gamma,
+                             double alpha, void* stream) {
+    clear_error();
+    RK_REQUIRE(dtype == RK_F32 || dtype == RK_F64, "rk_sap_update: bad dtype %d", dtype);
+    RK_REQUIRE(W && blk && D, "rk_sap_update: null pointer");
+    RK_REQUIRE(!accel || (V && Y), "rk_sap_update: the accelerated update needs V and Y");
+    RK_REQUIRE(n > 0 && k >= 1 && nb >= 1 && nb <= n && ldd >= k, "rk_sap_update: bad sizes");
+    RK_REQUIRE(ld == k, "rk_sap_update: iterates must be contiguous (ld == k)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 gd((unsigned)ceil_div(n * k, 256)), gb((unsigned)ceil_div(nb * k, 256));
+    if (dtype == RK_F32) {
+        if (accel)
+            hipLaunchKernelGGL((sap_dense_kernel<float>), gd, dim3(256), 0, st, n * k, (float*)W, (float*)V,
+                               (float*)Y, (float)beta, (float)alpha);
+        hipLaunchKernelGGL((sap_block_kernel<float>), gb, dim3(256), 0, st, nb, (int)k, blk, (const float*)D,
+                           ldd, (const float*)eta_dev, (float)eta_host, (float*)W, (float*)V, (float*)Y, ld,
+                           accel, (float)gamma, (float)alpha);
+    } else {
+        if (accel)
+            hipLaunchKernelGGL((sap_dense_kernel<double>), gd, dim3(256), 0, st, n * k, (double*)W, (double*)V,
+                               (double*)Y, beta, alpha);
+        hipLaunchKernelGGL((sap_block_kernel<double>), gb, dim3(256), 0, st, nb, (int)k, blk, (const double*)D,
+                           ldd, (const double*)eta_dev, eta_host, (double*)W, (double*)V, (double*)Y, ld, accel,
+                           gamma, alpha);
+    }
+    return launch_status("rk_sap_update");
+}
 
 extern "C" size_t rk_power_iteration_ws_bytes(int dtype, int64_t m, int64_t r) {
     if (m <= 0 || r < 0) return 0;

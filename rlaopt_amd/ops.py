@@ -503,6 +503,30 @@ class HipBackend:
         _lib.check(rc, "rk_power_iteration")
         return state
 
+    def sap_update(self, W, V, Y, blk, D, eta, accel, beta=0.0, gamma=0.0, alpha=0.0):
+        """In-place SAP iterate update (``rk_sap_update``); ``eta`` a float or a 0-dim device
+        tensor of the iterates' dtype.  Returns False when the layout is not supported."""
+        dev = _req(W, V, Y, blk, D)
+        n, k = W.shape
+        ok = W.is_contiguous() and D.shape == (blk.numel(), k) and D.stride(1) == 1 and blk.dtype == torch.int64
+        if accel:
+            ok = ok and V.is_contiguous() and Y.is_contiguous() and V.shape == W.shape == Y.shape
+        if not ok or D.dtype != W.dtype:
+            return False
+        eta_dev, eta_host = None, 0.0
+        if isinstance(eta, torch.Tensor):
+            _req(eta)
+            eta_dev = eta.reshape(1).to(W.dtype)
+        else:
+            eta_host = float(eta)
+        rc = self._lib.rk_sap_update(
+            _dt(W), n, k, _ptr(W), _ptr(V), _ptr(Y), k, _ptr(blk.contiguous()), blk.numel(), _ptr(D),
+            D.stride(0), _ptr(eta_dev), eta_host, int(bool(accel)), float(beta), float(gamma), float(alpha),
+            _stream(dev),
+        )
+        _lib.check(rc, "rk_sap_update")
+        return True
+
     def small_solve(self, A, B):
         """float64 device solve A X = B, A (k x k), B (k x nrhs), k, nrhs <= 16."""
         dev = _req(A, B)
@@ -582,7 +606,7 @@ def _guard_device(fn):
 
 for _name in ("gram_center", "kernel_materialize", "kernel_matmat", "sympack_materialize", "symm_matmat",
               "matmat", "rmatmat", "gemm", "gram_tn", "pcg_update_wr", "pcg_update_p", "axpby_cols",
-              "normal_pass", "small_solve", "sparse_sign_apply", "randn", "power_iteration"):
+              "normal_pass", "small_solve", "sparse_sign_apply", "randn", "power_iteration", "sap_update"):
     setattr(HipBackend, _name, _guard_device(getattr(HipBackend, _name)))
 del _name
 

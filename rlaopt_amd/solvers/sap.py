@@ -179,6 +179,19 @@ class SAP(Solver):
     def _get_block_update(self, W, B, blk, blk_precond):
         return blk_precond._inv @ self._block_gradient(W, B, blk)
 
+    def _fused_update(self, cols, blk_d, d, eta) -> bool:
+        """All columns active and device-resident iterates: the whole Nesterov bookkeeping in two
+        launches (``rk_sap_update``) instead of ~12 element-wise / index_put kernels."""
+        from ..ops import get_backend
+
+        be = get_backend()
+        if (not hasattr(be, "sap_update") or not self._W.is_cuda or cols.numel() != self._W.shape[1]
+                or os.environ.get("RK_SAP_FUSED_UPDATE", "1") == "0"):
+            return False
+        if self.accel:
+            return be.sap_update(self._W, self.V, self.Y, blk_d, d, eta, True, self.beta, self.gamma, self.alpha)
+        return be.sap_update(self._W, None, None, blk_d, d, eta, False)
+
     def _step(self):
         with quiet_host():
             self._step_impl()
@@ -229,6 +242,8 @@ class SAP(Solver):
             blk_precond, eta = self._precond_and_stepsize(blk)
             grad = self._block_gradient(loc, self.system.B[:, cols], blk_d)
         d = blk_precond._inv @ grad
+        if self._fused_update(cols, blk_d, d, eta):
+            return
         if not self.accel:
             Wm = self._W[:, cols]
             Wm[blk_d] -= eta * d

@@ -511,3 +511,34 @@ def test_power_iteration_matches_the_reference_loop(be, prec, precond):
         if rtol > 1e-6:  # (at rtol 1e-7 the float32 stopping decision is within rounding of the threshold)
             assert int(used) == its, (precond, max_iters, used, its)
             assert bool(done) == (err <= rtol * sig)
+
+
+@pytest.mark.parametrize("accel", [True, False])
+@pytest.mark.parametrize("eta_on_device", [True, False])
+def test_sap_update_matches_the_elementwise_formulas(be, prec, accel, eta_on_device):
+    """rk_sap_update against the reference's update lines (solvers/sap.py:139-175) written with
+    torch element-wise / index operations."""
+    dt = DTYPES[prec]
+    gen = torch.Generator().manual_seed(23)
+    n, k, nb = 1000, 3, 77
+    W, V, Y = (torch.randn(n, k, dtype=dt, generator=gen).to(dev()) for _ in range(3))
+    blk = torch.randperm(n, generator=gen)[:nb].to(dev())
+    d = torch.randn(nb, k, dtype=dt, generator=gen).to(dev())
+    eta, beta, gamma, alpha = 0.37, 0.9, 3.0, 0.25
+    W0, V0, Y0 = W.clone(), V.clone(), Y.clone()
+    if accel:
+        Wm = Y0.clone()
+        Wm[blk] -= eta * d
+        Vm = beta * V0 + (1 - beta) * Y0
+        Vm[blk] -= (eta * gamma) * d
+        want = (Wm, Vm, alpha * Vm + (1 - alpha) * Wm)
+    else:
+        Wm = W0.clone()
+        Wm[blk] -= eta * d
+        want = (Wm, V0, Y0)
+    e = torch.tensor(eta, dtype=dt, device=dev()) if eta_on_device else eta
+    assert be.sap_update(W, V if accel else None, Y if accel else None, blk, d, e, accel, beta, gamma, alpha)
+    tol = dict(rtol=1e-6, atol=1e-6) if dt == torch.float32 else dict(rtol=1e-14, atol=1e-14)
+    for got, ref in zip((W, V, Y), want):
+        torch.testing.assert_close(got, ref, **tol)
+    assert not be.sap_update(W.T, V, Y, blk, d, e, accel, beta, gamma, alpha)  # non-contiguous: declined
