@@ -18,4 +18,7 @@ timeout -k 10 300 python3 tools/bench_sap.py > $OUT/${TAG}_bench_sap.log 2>&1 &&
 timeout -k 10 300 python3 tools/bench_lsqr.py > $OUT/${TAG}_bench_lsqr.log 2>&1 && echo "lsqr ok" && tail -1 $OUT/${TAG}_bench_lsqr.log | cut -c1-300
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_sap -o ${TAG}_sap -- python3 tools/bench_sap.py --steps 10 > $OUT/${TAG}_sap_under_rocprof.log 2>&1 && echo "rocprof sap ok"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_lsqr -o ${TAG}_lsqr -- python3 tools/bench_lsqr.py > $OUT/${TAG}_lsqr_under_rocprof.log 2>&1 && echo "rocprof lsqr ok"
+# matrix-free kernel product: the three formulations side by side, then the matrix-core busy counter
+timeout -k 10 300 python3 tools/bench_kmatmat.py > $OUT/${TAG}_bench_kmatmat.log 2>&1 && echo "kmatmat ok" && grep -c Gpair $OUT/${TAG}_bench_kmatmat.log
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_kmatmat -o ${TAG} -- python3 tools/bench_kmatmat.py --modes bf16x3 --reps 2 --cases 200000x200000x64x1,200000x200000x32x1,5000x500000x50x10g > $OUT/${TAG}_pmc_kmatmat.log 2>&1 && echo "pmc kmatmat ok"
 ls -R $OUT | grep -c csv

@@ -118,6 +118,37 @@ with open(f"{dst}/{tag}_summary.md", "w") as f:
             f.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | "
                     f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
         f.write("\n")
+    # matrix-free kernel product (rk_kernel_matmat): formulations side by side + matrix-core counter
+    klog = f"{src}/{tag}_bench_kmatmat.log"
+    if os.path.exists(klog):
+        shutil.copy(klog, f"{dst}/{tag}_bench_kmatmat.log")
+        f.write("## Matrix-free kernel product `rk_kernel_matmat` (tools/bench_kmatmat.py)\n\n")
+        f.write("| case n1 x n2 x d x k (g: gathered rows) | bf16x3 Gpair/s | fp32 MFMA Gpair/s | direct VALU Gpair/s | "
+                "worst row error vs float64 (bf16x3 / fp32 MFMA / direct) |\n|---|---|---|---|---|\n")
+        for l in open(klog):
+            if not l.startswith("{"):
+                continue
+            r = json.loads(l)
+            g = lambda m, key: r.get(m, {}).get(key, float("nan"))  # noqa: E731
+            f.write(f"| {r['case']} | {g('bf16x3', 'Gpair_s'):.0f} | {g('mfma32', 'Gpair_s'):.0f} | "
+                    f"{g('direct', 'Gpair_s'):.0f} | {g('bf16x3', 'rel_err_rows'):.1e} / "
+                    f"{g('mfma32', 'rel_err_rows'):.1e} / {g('direct', 'rel_err_rows'):.1e} |\n")
+        f.write("\n")
+        kf = f"{src}/{tag}_pmc_kmatmat/{tag}_counter_collection.csv"
+        if os.path.exists(kf):
+            per = {}
+            for r in csv.DictReader(open(kf)):
+                if "kmat_matmat_bf16x3_kernel" in r["Kernel_Name"]:
+                    key = (r["Kernel_Name"].split("(")[0][-40:], r["Grid_Size"])
+                    per.setdefault(key, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            f.write("PMC (own pass, per launch): matrix-core busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)\n\n")
+            f.write("| kernel instantiation | grid | MFMA busy cycles | matrix-core busy |\n|---|---|---|---|\n")
+            for (kn, grid), c in per.items():
+                if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("GRBM_GUI_ACTIVE"):
+                    busy = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(c["SQ_VALU_MFMA_BUSY_CYCLES"])
+                    gui = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"])
+                    f.write(f"| `{kn}` | {grid} | {busy:.4g} | {100 * busy / (gui / 8.0 * 1024.0):.1f} % |\n")
+            f.write("\n")
     f.write("## HBM traffic of the shard product (separate --pmc passes)\n\n")
     f.write(f"FETCH_SIZE = {fetch:.0f} KB, WRITE_SIZE = {write:.0f} KB per launch -> "
             f"(2 x FETCH + WRITE) x 1024 = {traffic / 1e9:.2f} GB vs algorithmic {algo / 1e9:.2f} GB "
