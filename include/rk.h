@@ -84,14 +84,14 @@ int rk_kernel_matmat(int dtype, int kind,
                      const void* gram_center, void* ws, size_t ws_bytes, void* stream);
 
 /* `gram_center` (device, length d, same dtype; may be NULL) opts in to the matrix-core
- * formulation of the float32 product (RBF, Matern-3/2, Matern-5/2, d <= 64), which expands
+ * formulation of the float32 product (RBF, Matern-3/2, Matern-5/2, d <= 128), which expands
  * |x - y|^2 = |x'|^2 + |y'|^2 - 2 x'.y' with x' = (x - gram_center) / ell.  Its rounding error
  * grows with |x'|^2, so by passing a centre the caller vouches that
  *     max_i |(x_i - gram_center) / ell|^2 <= RK_GRAM_MAX_NORM2
  * over the rows of X1 and X2 (rk_kernel_gram_bound computes that maximum).  Entries then agree
  * with the direct (x - y)^2 evaluation to ~1e-5 absolute, the diagonal of K(X, X) included
  * (reference tolerance for float32: 1e-4, tests/kernels/test_standard.py).  NULL, float64,
- * Laplace, Matern-1/2 (not smooth in the squared distance) and d > 64 always take the direct-
+ * Laplace, Matern-1/2 (not smooth in the squared distance) and d > 128 always take the direct-
  * difference kernels.  pykeops (the reference's engine) evaluates the direct form. */
 #define RK_GRAM_MAX_NORM2 32.0
 

@@ -10,7 +10,7 @@
 //     h.h + (h.m + m.h) + (m.m + h.l + l.h)
 // - products of bf16 numbers are exact in float32 and the matrix cores accumulate in float32; the
 // three dropped terms (m.l, l.m, l.l) are below 2^-23 |x'||y'|, the rounding level of a float32 dot
-// product.  v_mfma_f32_16x16x32_bf16 retires 16 384 flop in 16 cycles per SIMD - 16 x the rate of
+// product.  d <= 128 (longer rows take the direct-difference kernels).  v_mfma_f32_16x16x32_bf16 retires 16 384 flop in 16 cycles per SIMD - 16 x the rate of
 // v_mfma_f32_32x32x2_f32 (4 096 flop in 64 cycles) - so six of them still cost 2.7 x less matrix-
 // core time than the float32 formulation (rk_kernelmfma.hip), and a d <= 32 system needs one k-step.
 //
@@ -33,20 +33,31 @@
 
 namespace rk {
 
-constexpr int BX_TJ = 64;                       // X2 points per tile (= points per image)
 constexpr int BX_TI = 128;                      // X1 points per workgroup (4 waves x 32)
-constexpr int BX_D = 64;                        // features per point in an image
-constexpr int BX_SPLIT = BX_TJ * BX_D * 2;      // bytes of one split of one image (8 KiB)
+constexpr int BX_SPLIT = 8192;                  // bytes of one split of one image
 constexpr int BX_IMG = 3 * BX_SPLIT;            // bytes of one image (24 KiB)
 constexpr int BX_LDV = 20;                      // stride of the V tile rows (conflict-free A operand reads)
-constexpr int BX_FOLD = 32;                     // tiles between folds of the running sums (2 048 columns)
+constexpr int BX_VROWS = 64;                    // rows of the V / |y|^2 tiles in LDS (largest tile)
+constexpr int BX_FOLD_COLS = 2048;              // columns between folds of the running sums
+
+// Image geometry: FEAT = 64 features per point (d <= 64: 64 points per image = X2 points per tile) or
+// 128 (d <= 128: 32 points per image), either way 24 KiB per image.  A point's split is one row of
+// FEAT bf16; its 16-byte chunks are XOR-swizzled with the row index so that the 16 rows of a
+// ds_read_b128 lane group fall into 16 distinct 16-byte slots of the 256-byte bank row.
+template <int FEAT>
+struct BxGeo {
+    static constexpr int TJ = BX_SPLIT / (FEAT * 2);  // points per image: 64 or 32
+    static constexpr int ROWB = FEAT * 2;             // bytes of one point in one split
+    static constexpr int CPR = FEAT / 8;              // 16-byte chunks per row: 8 or 16
+    static constexpr int JB = TJ / 16;                // 16-point block rows per tile
+    __host__ __device__ static int chunk(int r, int c) {
+        return r * ROWB + ((c ^ (FEAT == 64 ? ((r >> 1) & 7) : (r & 15))) << 4);
+    }
+};
 
 typedef __bf16 bx_frag __attribute__((ext_vector_type(8)));
 typedef float bx_acc __attribute__((ext_vector_type(4)));
 typedef unsigned int bx_u4 __attribute__((ext_vector_type(4)));
-
-// byte offset of 16-byte chunk c (8 features) of point r inside one split of an image
-__device__ __forceinline__ int bx_chunk(int r, int c) { return r * (BX_D * 2) + ((c ^ ((r >> 1) & 7)) << 4); }
 
 __device__ __forceinline__ unsigned bx_bf16_rn(float x) {  // round to nearest even, finite x
     unsigned u = __float_as_uint(x);
@@ -56,14 +67,16 @@ __device__ __forceinline__ unsigned bx_bf16_rn(float x) {  // round to nearest e
 
 // One thread per (point, 8-feature chunk): gather, centre, scale, split, swizzle, |x'|^2.
 // Points n .. npad - 1 (padding of the last image) are written as zeros; `norms` has npad entries.
+template <int FEAT>
 __global__ void __launch_bounds__(256)
 gram_split_kernel(const float* __restrict__ X, int64_t ldx, const int64_t* __restrict__ idx, int64_t n,
                   int64_t npad, int64_t d, const float* __restrict__ iw, const float* __restrict__ muw,
                   unsigned char* __restrict__ img, float* __restrict__ norms) {
+    using G = BxGeo<FEAT>;
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t p = g >> 3;
-    const int c = (int)(g & 7);
-    if (p >= npad) return;  // (whole groups of 8 lanes: npad * 8 is a multiple of 64)
+    const int64_t p = g / G::CPR;
+    const int c = (int)(g % G::CPR);
+    if (p >= npad) return;  // (whole groups of CPR lanes: npad * CPR is a multiple of 64)
     const bool live = p < n;
     const float* row = live ? X + (idx ? idx[p] : p) * ldx : nullptr;
     unsigned hs[8], ms[8], ls[8];
@@ -79,13 +92,12 @@ gram_split_kernel(const float* __restrict__ X, int64_t ldx, const int64_t* __res
         const float r2 = r1 - __uint_as_float(m << 16);  // exact
         hs[u] = h; ms[u] = m; ls[u] = bx_bf16_rn(r2);
     }
-    ss += __shfl_xor(ss, 1);
-    ss += __shfl_xor(ss, 2);
-    ss += __shfl_xor(ss, 4);
+#pragma unroll
+    for (int sh = 1; sh < G::CPR; sh <<= 1) ss += __shfl_xor(ss, sh);
     // padding points get a huge |x'|^2: their kernel value is exactly 0 whatever V holds there
     if (c == 0) norms[p] = live ? ss : 1e24f;
-    const int r = (int)(p & (BX_TJ - 1));
-    unsigned char* dst = img + (p >> 6) * BX_IMG + bx_chunk(r, c);
+    const int r = (int)(p % G::TJ);
+    unsigned char* dst = img + (p / G::TJ) * BX_IMG + G::chunk(r, c);
     auto pack = [](const unsigned* e) {
         bx_u4 o;
         o.x = e[0] | (e[1] << 16); o.y = e[2] | (e[3] << 16); o.z = e[4] | (e[5] << 16); o.w = e[6] | (e[7] << 16);
@@ -96,10 +108,10 @@ gram_split_kernel(const float* __restrict__ X, int64_t ldx, const int64_t* __res
     *reinterpret_cast<bx_u4*>(dst + 2 * BX_SPLIT) = pack(ls);
 }
 
-constexpr size_t BX_SMEM_BYTES = 2 * BX_IMG + 2 * BX_TJ * BX_LDV * sizeof(float) + 2 * BX_TJ * sizeof(float);
+constexpr size_t BX_SMEM_BYTES = 2 * BX_IMG + 2 * BX_VROWS * BX_LDV * sizeof(float) + 2 * BX_VROWS * sizeof(float);
 
 // KV = 0: second product on the float32 matrix cores (k <= 16); KV = 1 / 2 / 4: on the VALU (k <= KV)
-// NKS = k-steps of 32 features (1: d <= 32, 2: d <= 64)
+// NKS = k-steps of 32 features (1: d <= 32, 2: d <= 64, 4: d <= 128 - half-height tiles)
 // (A hand-ordered instruction stream - operand reads one step ahead, kappa of block row jb - 1 placed in
 // the shadow of the MFMAs of block row jb with sched_barrier - was 3 - 11 % SLOWER than the compiler's
 // order: two workgroups per CU already overlap one wave's kappa with the other's MFMAs.)
@@ -110,10 +122,12 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
                           const float* __restrict__ ny, const float* __restrict__ V, int k, int64_t ldv,
                           int64_t tiles_per_seg, float* __restrict__ part, float* __restrict__ Y, int64_t ldy,
                           int accumulate) {
+    using G = BxGeo<(NKS <= 2 ? 64 : 128)>;
+    constexpr int TJ = G::TJ;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* XB = smem;                                                  // [2][BX_IMG]
-    float* VS = reinterpret_cast<float*>(smem + 2 * BX_IMG);                   // [2][BX_TJ][BX_LDV]
-    float* NY = VS + 2 * BX_TJ * BX_LDV;                                       // [2][BX_TJ]
+    float* VS = reinterpret_cast<float*>(smem + 2 * BX_IMG);                   // [2][BX_VROWS][BX_LDV]
+    float* NY = VS + 2 * BX_VROWS * BX_LDV;                                    // [2][BX_VROWS]
     const float rbf_c = -0.5f * w * w * 1.4426950408889634f;  // exp(-s w^2 / 2) = exp2(rbf_c s)
     const float m2c = -2.f * rbf_c;
 
@@ -121,7 +135,7 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
     const int lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
     const int64_t i0 = (int64_t)blockIdx.x * BX_TI;
-    const int64_t ntile = (n2 + BX_TJ - 1) / BX_TJ;
+    const int64_t ntile = (n2 + TJ - 1) / TJ;
     const int64_t t_lo = (int64_t)blockIdx.y * tiles_per_seg;
     const int64_t t_hi = (t_lo + tiles_per_seg < ntile) ? t_lo + tiles_per_seg : ntile;
 
@@ -131,11 +145,11 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib) {
         const int64_t ip = i0 + wave * 32 + ib * 16 + lr;  // < round_up(n1, 128): the images exist
-        const int r = (int)(ip & (BX_TJ - 1));
-        const unsigned char* base = img1 + (ip >> 6) * BX_IMG;
+        const int r = (int)(ip % TJ);
+        const unsigned char* base = img1 + (ip / TJ) * BX_IMG;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            const unsigned char* src = base + bx_chunk(r, 4 * ks + lq);
+            const unsigned char* src = base + G::chunk(r, 4 * ks + lq);
             bh[ib][ks] = __builtin_bit_cast(bx_frag, *reinterpret_cast<const bx_u4*>(src));
             bm[ib][ks] = __builtin_bit_cast(bx_frag, *reinterpret_cast<const bx_u4*>(src + BX_SPLIT));
             bl[ib][ks] = __builtin_bit_cast(bx_frag, *reinterpret_cast<const bx_u4*>(src + 2 * BX_SPLIT));
@@ -156,25 +170,25 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
         const bx_u4* src = reinterpret_cast<const bx_u4*>(img2 + t * BX_IMG);
 #pragma unroll
         for (int q = 0; q < 6; ++q) pre[q] = src[tid + 256 * q];
-        const int64_t j = t * BX_TJ + (tid >> 2);
+        const int64_t j = t * TJ + ((tid >> 2) & (TJ - 1));
         const float* vrow = V + (j < n2 ? j : n2 - 1) * ldv;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = (tid & 3) * 4 + u;
             vr[u] = vrow[c < k ? c : k - 1];
         }
-        nyr = ny[t * BX_TJ + (tid & (BX_TJ - 1))];  // (ny has round_up(n2, 64) entries)
+        nyr = ny[t * TJ + (tid & (TJ - 1))];  // (ny has round_up(n2, 64) entries)
     };
     auto store_tile = [&](int buf) {
         bx_u4* dst = reinterpret_cast<bx_u4*>(XB + buf * BX_IMG);
 #pragma unroll
         for (int q = 0; q < 6; ++q) dst[tid + 256 * q] = pre[q];
-        float* vs = VS + buf * BX_TJ * BX_LDV + (tid >> 2) * BX_LDV + (tid & 3) * 4;
-        *reinterpret_cast<float4*>(vs) = make_float4(vr[0], vr[1], vr[2], vr[3]);
-        if (tid < BX_TJ) NY[buf * BX_TJ + tid] = nyr * (RBF ? rbf_c : 1.f);
+        float* vs = VS + buf * BX_VROWS * BX_LDV + (tid >> 2) * BX_LDV + (tid & 3) * 4;
+        if (tid < 4 * TJ) *reinterpret_cast<float4*>(vs) = make_float4(vr[0], vr[1], vr[2], vr[3]);
+        if (tid < TJ) NY[buf * BX_VROWS + tid] = nyr * (RBF ? rbf_c : 1.f);
     };
 
-    // running sums, two-level (folded every BX_FOLD tiles)
+    // running sums, two-level (folded every BX_FOLD_COLS columns)
     bx_acc yacc[2], ytot[2];
     constexpr int KVN = KV > 0 ? KV : 1;
     float yv[2][KVN], yvt[2][KVN];
@@ -200,10 +214,10 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
         store_tile(buf ^ 1);
         load_tile(t + 2 < t_hi ? t + 2 : t_last);
         const unsigned char* xb = XB + buf * BX_IMG;
-        const float* vsb = VS + buf * BX_TJ * BX_LDV;
-        const float* nyb = NY + buf * BX_TJ;
+        const float* vsb = VS + buf * BX_VROWS * BX_LDV;
+        const float* nyb = NY + buf * BX_VROWS;
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
+        for (int jb = 0; jb < G::JB; ++jb) {
             // ---- S^T block row jb: 16 points of X2 against this wave's 2 x 16 points of X1 -------
             bx_acc acc[2];
 #pragma unroll
@@ -213,7 +227,7 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
             const int r = jb * 16 + lr;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                const unsigned char* src = xb + bx_chunk(r, 4 * ks + lq);
+                const unsigned char* src = xb + G::chunk(r, 4 * ks + lq);
                 const bx_frag ah = *reinterpret_cast<const bx_frag*>(src);
                 const bx_frag am = *reinterpret_cast<const bx_frag*>(src + BX_SPLIT);
                 const bx_frag al = *reinterpret_cast<const bx_frag*>(src + 2 * BX_SPLIT);
@@ -267,7 +281,7 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
                 }
             }
         }
-        if (((t - t_lo) & (BX_FOLD - 1)) == BX_FOLD - 1) {
+        if (((t - t_lo) & (BX_FOLD_COLS / TJ - 1)) == BX_FOLD_COLS / TJ - 1) {
 #pragma unroll
             for (int ib = 0; ib < 2; ++ib) {
                 ytot[ib] += yacc[ib];
@@ -317,13 +331,15 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
     }
 }
 
-// workspace behind the partial sums: affine map (2 x 64 floats), |x'|^2 of both sets, the images
+// workspace behind the partial sums: affine map (2 x 128 floats), |x'|^2 of both sets (padded), the
+// images (sized for the 128-feature geometry: 768 bytes per point)
 static size_t bx_float_bytes(int64_t n1, int64_t n2) {
-    return (size_t)round_up((2 * 64 + round_up(n1, BX_TI) + round_up(n2, BX_TJ)) * (int64_t)sizeof(float), 256);
+    return (size_t)round_up((2 * 128 + round_up(n1, BX_TI) + round_up(n2, 64)) * (int64_t)sizeof(float), 256);
 }
 size_t bx_aux_bytes(int64_t n1, int64_t n2) {
-    return bx_float_bytes(n1, n2) + (size_t)(round_up(n1, BX_TI) / BX_TJ + round_up(n2, BX_TJ) / BX_TJ) * BX_IMG;
+    return bx_float_bytes(n1, n2) + (size_t)(round_up(n1, BX_TI) / 32 + round_up(n2, 64) / 32) * BX_IMG;
 }
+int64_t bx_tile_points(int64_t d) { return d <= 64 ? 64 : 32; }
 
 void gram_prep_launch(const float* center, const float* ell_vec, int64_t d, float* iw, float* muw, hipStream_t st);
 
@@ -332,19 +348,27 @@ int launch_kmatmat_bf16x3(int kind, const float* X1, int64_t n1, int64_t ldx1, c
                           const float* ell_vec, const float* center, float scale, const float* V, int k,
                           int64_t ldv, int64_t S, int64_t tiles_per_seg, void* aux, float* part, float* Y,
                           int64_t ldy, int accumulate, hipStream_t st) {
+    const int64_t tj = bx_tile_points(d);
     float* iw = static_cast<float*>(aux);
-    float* muw = iw + 64;
-    float* nxp = muw + 64;
-    const int64_t n1pad = round_up(n1, BX_TI), n2pad = round_up(n2, BX_TJ);
+    float* muw = iw + 128;
+    float* nxp = muw + 128;
+    const int64_t n1pad = round_up(n1, BX_TI), n2pad = round_up(n2, 64);
     float* nyp = nxp + n1pad;
     unsigned char* img1 = static_cast<unsigned char*>(aux) + bx_float_bytes(n1, n2);
-    unsigned char* img2 = img1 + (n1pad / BX_TJ) * BX_IMG;
+    unsigned char* img2 = img1 + (n1pad / tj) * BX_IMG;
     gram_prep_launch(center, ell_vec, d, iw, muw, st);
-    hipLaunchKernelGGL(gram_split_kernel, dim3((unsigned)ceil_div(n1pad * 8, 256)), dim3(256), 0, st, X1, ldx1,
-                       idx1, n1, n1pad, d, iw, muw, img1, nxp);
-    hipLaunchKernelGGL(gram_split_kernel, dim3((unsigned)ceil_div(n2pad * 8, 256)), dim3(256), 0, st, X2, ldx2,
-                       idx2, n2, n2pad, d, iw, muw, img2, nyp);
-    const bool one_step = d <= 32;
+    if (tj == 64) {
+        hipLaunchKernelGGL(gram_split_kernel<64>, dim3((unsigned)ceil_div(n1pad * 8, 256)), dim3(256), 0, st, X1,
+                           ldx1, idx1, n1, n1pad, d, iw, muw, img1, nxp);
+        hipLaunchKernelGGL(gram_split_kernel<64>, dim3((unsigned)ceil_div(n2pad * 8, 256)), dim3(256), 0, st, X2,
+                           ldx2, idx2, n2, n2pad, d, iw, muw, img2, nyp);
+    } else {
+        hipLaunchKernelGGL(gram_split_kernel<128>, dim3((unsigned)ceil_div(n1pad * 16, 256)), dim3(256), 0, st, X1,
+                           ldx1, idx1, n1, n1pad, d, iw, muw, img1, nxp);
+        hipLaunchKernelGGL(gram_split_kernel<128>, dim3((unsigned)ceil_div(n2pad * 16, 256)), dim3(256), 0, st, X2,
+                           ldx2, idx2, n2, n2pad, d, iw, muw, img2, nyp);
+    }
+    const int nks = d <= 32 ? 1 : (d <= 64 ? 2 : 4);
     dim3 grid((unsigned)ceil_div(n1, BX_TI), (unsigned)S);
 #define RK_BX_N(RBFV, KVV, NKSV)                                                                           \
     hipLaunchKernelGGL((kmat_matmat_bf16x3_kernel<RBFV, KVV, NKSV>), grid, dim3(256), BX_SMEM_BYTES, st,   \
@@ -352,14 +376,15 @@ int launch_kmatmat_bf16x3(int kind, const float* X1, int64_t n1, int64_t ldx1, c
                        accumulate)
 #define RK_BX(RBFV, KVV)                                                                                   \
     do {                                                                                                   \
-        if (one_step) RK_BX_N(RBFV, KVV, 1);                                                               \
-        else RK_BX_N(RBFV, KVV, 2);                                                                        \
+        if (nks == 1) RK_BX_N(RBFV, KVV, 1);                                                               \
+        else if (nks == 2) RK_BX_N(RBFV, KVV, 2);                                                          \
+        else RK_BX_N(RBFV, KVV, 4);                                                                        \
     } while (0)
 #define RK_BX_K(RBFV)                                                                                      \
     do {                                                                                                   \
         if (k == 1) RK_BX(RBFV, 1);                                                                        \
         else if (k == 2) RK_BX(RBFV, 2);                                                                   \
-        else if (k <= 4) RK_BX(RBFV, 4);                                                                   \
+        else if (k <= 4) RK_BX(RBFV, 4);                                                        \
         else RK_BX(RBFV, 0);                                                                               \
     } while (0)
     if (kind == RK_RBF) RK_BX_K(true);

@@ -644,7 +644,7 @@ int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, con
                         int64_t tiles_per_seg, float* norms, float* part, float* Y, int64_t ldy,
                         int accumulate, hipStream_t st);
 
-// float32, kernels smooth in the squared distance (RBF, Matern-3/2, -5/2), d <= 64, and a
+// float32, kernels smooth in the squared distance (RBF, Matern-3/2, -5/2), d <= 128 (bf16) / 64 (fp32), and a
 // `gram_center` from the caller (who thereby vouches for the norm bound, see rk.h): the matrix-core
 // formulation (rk_kernelmfma.hip; 1.4 - 2.2x the VALU kernels: 711 vs 330 Gpair/s at d = 64,
 // 470 vs 281 at d = 50, k = 10).  Scalar and per-feature lengthscales both.
@@ -652,9 +652,9 @@ int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, con
 #ifndef RK_KMAT_MFMA_DMIN
 #define RK_KMAT_MFMA_DMIN 1
 #endif
-static bool kmat_use_mfma(bool is_f32, int kind, const void* center, int64_t d, int64_t n1, int64_t n2) {
-    if (!(is_f32 && center != nullptr && kind != RK_LAPLACE && kind != RK_MATERN12 &&
-          d >= RK_KMAT_MFMA_DMIN && d <= 64 && n2 >= 128 && n1 >= 1))
+static bool kmat_use_gram(int kind, const void* center, int64_t d, int64_t dmax, int64_t n1, int64_t n2) {
+    if (!(center != nullptr && kind != RK_LAPLACE && kind != RK_MATERN12 && d >= RK_KMAT_MFMA_DMIN &&
+          d <= dmax && n2 >= 128 && n1 >= 1))
         return false;
     const char* e = getenv("RK_KMAT_MFMA");
     return !(e != nullptr && e[0] == '0');
@@ -664,6 +664,7 @@ static bool kmat_use_mfma(bool is_f32, int kind, const void* center, int64_t d, 
 // (three-way bf16 split of every coordinate, six partial products: float32 accuracy at 2.7 x less
 // matrix-core time).  RK_KMAT_BF16X3=0 (read per call) keeps the float32 MFMA kernel.
 size_t bx_aux_bytes(int64_t n1, int64_t n2);
+int64_t bx_tile_points(int64_t d);
 int launch_kmatmat_bf16x3(int kind, const float* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
                           const float* X2, int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d, float w,
                           const float* ell_vec, const float* center, float scale, const float* V, int k,
@@ -675,11 +676,12 @@ static bool kmat_use_bf16x3() {
     return !(e != nullptr && e[0] == '0');
 }
 
-static KMPlan plan_kmatmat_bf16(int64_t n1, int64_t n2) {
+static KMPlan plan_kmatmat_bf16(int64_t n1, int64_t n2, int64_t tile_points) {
     const int64_t row_blocks = ceil_div(n1, 128);
-    const int64_t ntile = ceil_div(n2, 64);
+    const int64_t ntile = ceil_div(n2, tile_points);
     int64_t S = ceil_div(4096, row_blocks);  // 512 workgroups are resident: >= 8 rounds (short tail)
-    if (S > ntile / 8) S = ntile / 8;        // >= 8 column tiles per workgroup
+    const int64_t min_tiles = 512 / tile_points;  // >= 512 columns per workgroup
+    if (S > ntile / min_tiles) S = ntile / min_tiles;
     if (S < 1) S = 1;
     KMPlan p;
     p.tiles_per_seg = ceil_div(ntile, S);
@@ -702,8 +704,8 @@ static KMPlan plan_kmatmat_mfma(int64_t n1, int64_t n2) {
 static size_t kmat_norms_offset(int64_t S, int64_t n1, int64_t k) {  // norms sit behind the partials
     return round_up((size_t)(S > 1 ? S : 0) * n1 * k * sizeof(float), 256);
 }
-static size_t kmat_norms_bytes(int64_t n1, int64_t n2) {  // affine map (2 x 64) + |x'|^2 of both sets
-    return (size_t)(2 * 64 + n1 + n2) * sizeof(float);
+static size_t kmat_norms_bytes(int64_t n1, int64_t n2) {  // affine map (2 x 128) + |x'|^2 of both sets
+    return (size_t)(2 * 128 + n1 + n2) * sizeof(float);
 }
 
 template <typename T>
@@ -714,8 +716,8 @@ static int kmatmat_impl(int kind, const T* X1, int64_t n1, int64_t ldx1, const i
                         size_t ws_bytes, hipStream_t st) {
     const T w = ell_vec ? T(1) : T(1.0 / ell);
     if constexpr (sizeof(T) == 4) {
-        if (kmat_use_mfma(true, kind, gram_center, d, n1, n2) && kmat_use_bf16x3()) {
-            const KMPlan pb = plan_kmatmat_bf16(n1, n2);
+        if (kmat_use_gram(kind, gram_center, d, 128, n1, n2) && kmat_use_bf16x3()) {
+            const KMPlan pb = plan_kmatmat_bf16(n1, n2, bx_tile_points(d));
             const size_t off = kmat_norms_offset(pb.S, n1, k);
             const size_t need = off + bx_aux_bytes(n1, n2);
             if (ws == nullptr || ws_bytes < need) {
@@ -731,7 +733,7 @@ static int kmatmat_impl(int kind, const T* X1, int64_t n1, int64_t ldx1, const i
                                0, st, partb, (int)pb.S, n1, (int)k, (T)scale, Y, ldy, accumulate);
             return launch_status("rk_kernel_matmat(finish)");
         }
-        if (kmat_use_mfma(true, kind, gram_center, d, n1, n2)) {
+        if (kmat_use_gram(kind, gram_center, d, 64, n1, n2)) {
             const KMPlan pm = plan_kmatmat_mfma(n1, n2);
             const size_t off = kmat_norms_offset(pm.S, n1, k);
             const size_t need = off + kmat_norms_bytes(n1, n2);
@@ -844,9 +846,11 @@ extern "C" size_t rk_kernel_matmat_ws_bytes(int dtype, int64_t n1, int64_t n2, i
         const KMPlan pm = plan_kmatmat_mfma(n1, n2);
         const size_t m = kmat_norms_offset(pm.S, n1, k) + kmat_norms_bytes(n1, n2);
         if (m > bytes) bytes = m;
-        const KMPlan pb = plan_kmatmat_bf16(n1, n2);
-        const size_t b = kmat_norms_offset(pb.S, n1, k) + bx_aux_bytes(n1, n2);
-        if (b > bytes) bytes = b;
+        for (int64_t tp = 32; tp <= 64; tp *= 2) {  // (d is not an argument: both tile geometries)
+            const KMPlan pb = plan_kmatmat_bf16(n1, n2, tp);
+            const size_t b = kmat_norms_offset(pb.S, n1, k) + bx_aux_bytes(n1, n2);
+            if (b > bytes) bytes = b;
+        }
     }
     return bytes;
 }

@@ -46,9 +46,10 @@ typedef float mf_acc __attribute__((ext_vector_type(16)));
 
 // per-feature affine map of the staged panels: x' = x * iw[c] - muw[c] with iw = 1/ell_c (1 for a
 // scalar lengthscale, which kappa applies) and muw = centre_c * iw[c]; entries c >= d are zero
+constexpr int GRAM_DMAX = 128;  // features the map covers (rk_kernelbf16.hip goes up to d = 128)
 __global__ void gram_prep_kernel(const float* __restrict__ center, const float* __restrict__ ell_vec,
                                  int64_t d, float* __restrict__ iw, float* __restrict__ muw) {
-    const int c = threadIdx.x;  // MF_D threads
+    const int c = threadIdx.x;  // GRAM_DMAX threads
     float a = 0.f, b = 0.f;
     if (c < d) {
         a = ell_vec ? 1.f / ell_vec[c] : 1.f;
@@ -60,7 +61,7 @@ __global__ void gram_prep_kernel(const float* __restrict__ center, const float* 
 
 void gram_prep_launch(const float* center, const float* ell_vec, int64_t d, float* iw, float* muw,
                       hipStream_t st) {
-    hipLaunchKernelGGL(gram_prep_kernel, dim3(1), dim3(MF_D), 0, st, center, ell_vec, d, iw, muw);
+    hipLaunchKernelGGL(gram_prep_kernel, dim3(1), dim3(GRAM_DMAX), 0, st, center, ell_vec, d, iw, muw);
 }
 
 // |row'|^2 of gathered, centred, scaled rows: out[p] = sum_c (X[row(p)][c] iw[c] - muw[c])^2.
@@ -364,8 +365,8 @@ kmat_matmat_mfma_kernel(int kind, const float* __restrict__ X1, int64_t n1, int6
 constexpr size_t MF_SMEM_BYTES =
     sizeof(float) * (2 * MF_D * MF_LD + MF_T * MF_LDV + MF_T + 2 * MF_D);  // S1 + S2 + VS + NY + IW + MUW
 
-// launch (float32 only): the affine map (2 * MF_D floats) and the norms of both point sets go into
-// `norms` (2 * MF_D + n1 + n2 floats), then the tiles
+// launch (float32 only): the affine map (2 * GRAM_DMAX floats) and the norms of both point sets go into
+// `norms` (2 * GRAM_DMAX + n1 + n2 floats), then the tiles
 int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
                         const float* X2, int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d,
                         float w, const float* ell_vec, const float* center, float scale, const float* V,
@@ -373,10 +374,10 @@ int launch_kmatmat_mfma(int kind, const float* X1, int64_t n1, int64_t ldx1, con
                         int64_t tiles_per_seg, float* norms, float* part, float* Y, int64_t ldy,
                         int accumulate, hipStream_t st) {
     float* iw = norms;
-    float* muw = norms + MF_D;
-    float* nxp = norms + 2 * MF_D;
+    float* muw = norms + GRAM_DMAX;
+    float* nxp = norms + 2 * GRAM_DMAX;
     float* nyp = nxp + n1;
-    hipLaunchKernelGGL(gram_prep_kernel, dim3(1), dim3(MF_D), 0, st, center, ell_vec, d, iw, muw);
+    gram_prep_launch(center, ell_vec, d, iw, muw, st);
     hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)ceil_div(n1, 16)), dim3(256), 0, st, X1, ldx1,
                        idx1, n1, d, iw, muw, nxp);
     hipLaunchKernelGGL(row_norms_kernel, dim3((unsigned)ceil_div(n2, 16)), dim3(256), 0, st, X2, ldx2,

@@ -86,7 +86,7 @@ def _gram_center(kind: str, A1: torch.Tensor, A2: torch.Tensor, lengthscale, dev
     """Centre for the matrix-core formulation of matrix-free products over (subsets of) the rows
     of A1 and A2, or None (``HipBackend.gram_center``; one host read-back, so operators cache the
     answer - the point sets of an operator never change)."""
-    if kind in ("laplace", "matern12") or A1.dtype != torch.float32 or A1.shape[1] > 64:
+    if kind in ("laplace", "matern12") or A1.dtype != torch.float32 or A1.shape[1] > 128:
         return None
     be = get_backend()
     if not hasattr(be, "gram_center"):

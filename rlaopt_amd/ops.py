@@ -165,12 +165,12 @@ class HipBackend:
 
     def gram_center(self, X1, X2, lengthscale):
         """Centre c (length-d tensor) for the matrix-core formulation of the matrix-free float32
-        product, or None when the data do not qualify: float32 only, d <= 64, and
+        product, or None when the data do not qualify: float32 only, d <= 128, and
         max |(x - c) / ell|^2 <= RK_GRAM_MAX_NORM2 over the rows of X1 and X2 (include/rk.h).
         One small device reduction and ONE host read-back: operators call it once per point set
         (gathered subsets inherit the bound) and hand the result to ``kernel_matmat``."""
         dev = _req(X1, X2)
-        if X1.dtype != torch.float32 or X2.dtype != torch.float32 or X1.shape[1] > 64:
+        if X1.dtype != torch.float32 or X2.dtype != torch.float32 or X1.shape[1] > 128:
             return None
         ell_vec, ell = None, 1.0
         if isinstance(lengthscale, torch.Tensor):

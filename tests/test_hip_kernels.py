@@ -324,7 +324,8 @@ def test_normal_pass_unsupported_shapes(be):
     assert be.normal_pass(A5, torch.randn(66, 1, device=dev()), torch.randn(100, 1, device=dev()), c) is None
 
 
-@pytest.mark.parametrize("n1,n2,d,k", [(129, 1000, 50, 10), (300, 515, 64, 1), (64, 128, 33, 16), (500, 2100, 8, 4)])
+@pytest.mark.parametrize("n1,n2,d,k", [(129, 1000, 50, 10), (300, 515, 64, 1), (64, 128, 33, 16), (500, 2100, 8, 4),
+                                       (257, 700, 100, 1), (130, 4500, 128, 3), (200, 333, 65, 10), (300, 400, 97, 2)])
 def test_kernel_matmat_matrix_core_formulation(be, monkeypatch, n1, n2, d, k):
     """The matrix-core formulation (float32 kernels smooth in the squared distance, d <= 64, data
     inside the norm bound: S = X2' X1'^T on the fp32 MFMA, |x'|^2 + |y'|^2 - 2 S, kappa on the
@@ -370,7 +371,7 @@ def _columns(be, kind, X1d, X2d, ls, cols, idx1=None, idx2=None, **kw):
 
 @pytest.mark.parametrize("kind", ["rbf", "matern32", "matern52"])
 @pytest.mark.parametrize("ell", ["scalar", "ard"])
-@pytest.mark.parametrize("data", ["unit", "offset"])
+@pytest.mark.parametrize("data", ["unit", "offset", "unit_d100"])
 def test_matrix_core_formulation_entrywise_on_the_diagonal(be, monkeypatch, kind, ell, data):
     """ENTRY-WISE agreement of the matrix-core formulation with the direct-difference evaluation
     (``kernel_materialize``: what pykeops computes) for X1 is X2 - the diagonal K(x, x) = 1, where
@@ -378,9 +379,9 @@ def test_matrix_core_formulation_entrywise_on_the_diagonal(be, monkeypatch, kind
     (mean 10, std 1, lengthscale 8: without the centring of the panels the expansion is off by
     1e-2), with scalar and per-feature lengthscales, with and without index gathers."""
     dt = torch.float32
-    n, d, k = 700, 64, 16
+    n, d, k = 700, (100 if data == "unit_d100" else 64), 16
     gen = torch.Generator().manual_seed(11)
-    if data == "unit":
+    if data != "offset":
         X = torch.randn(n, d, dtype=dt, generator=gen) / d**0.5
         base_ell = 1.0
     else:

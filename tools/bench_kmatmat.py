@@ -31,7 +31,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--cases", default="200000x200000x64x1,200000x200000x32x1,5000x500000x50x10g,"
-                                       "25000x200000x64x1,200000x200000x64x4,5000x500000x50x16g,50000x50000x32x1")
+                                       "25000x200000x64x1,200000x200000x64x4,5000x500000x50x16g,50000x50000x32x1,"
+                                       "100000x100000x100x1,100000x100000x128x10")
     ap.add_argument("--modes", default="bf16x3,mfma32,direct")
     ap.add_argument("--kind", default="rbf")
     args = ap.parse_args()
