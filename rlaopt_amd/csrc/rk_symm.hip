@@ -285,15 +285,178 @@ symm_strip_kernel(const TS* __restrict__ Kp, SymLayout L, const T* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// the strip product for 5 .. 16 right-hand sides (float32): both uses of a stored entry on the
+// float32 matrix cores
+// ------------------------------------------------------------------------------------------
+// At 16 right-hand sides every loaded element feeds 32 FMAs: 104 TFLOP/s at the HBM rate - more
+// than the vector units deliver, 66 % of the fp32 matrix peak.  A workgroup stages 32-row tiles of
+// its item (32 x 256 floats = 32 KiB, double-buffered, register-staged two tiles ahead like
+// rk_kernelbf16.hip) in LDS and both products read their v_mfma_f32_16x16x4_f32 A operands from
+// there with ds_read_b128 (4 MFMAs per read):
+//   row part  Yrow[32 x 16] = T[32 x 256] V[256 x 16]:  lane (row = lane % 16, 4 columns at
+//             16 s + 4 (lane / 16)); wave (rb, half) owns 16 rows x 128 columns, its 32 B operands
+//             (V of those columns) stay in registers for the whole item; the two column halves are
+//             added through LDS and go to the (strip, row) table;
+//   col part  Ycol[256 x 16] += T^T[256 x 32] V_i[32 x 16]:  lane (column group = lane % 16, row
+//             4 s + lane / 16); wave w owns columns 64 w .. 64 w + 63, 16 accumulator registers for
+//             the whole item, written to the (item, column) table at its end.
+// The 16-byte chunks of a staged row are XOR-swizzled with the row index: both read patterns (16
+// rows x one chunk, one row x 16 chunks) are bank-conflict free.  V is first copied into a zero-
+// padded [round_up(n, 256)][16] array so that every operand load is an aligned, unconditional one.
+constexpr int SMK = 16;                        // right-hand sides carried (k is padded up to it)
+constexpr int SM_TR = 32;                      // rows per tile
+constexpr size_t SM_SMEM_BYTES = (2 * SM_TR * 256 + 2 * SM_TR * SMK + 2 * 2 * SM_TR * SMK) * sizeof(float);
+
+typedef float sm_acc __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256)
+symm_pad_v_kernel(const float* __restrict__ V, int64_t n, int64_t npad, int k, int64_t ldv, float* __restrict__ Vp) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= npad * SMK) return;
+    const int64_t i = e / SMK;
+    const int c = (int)(e - i * SMK);
+    Vp[e] = (i < n && c < k) ? V[i * ldv + c] : 0.f;
+}
+
+__device__ __forceinline__ int sm_at(int row, int chunk) {  // float index of 16-byte chunk `chunk` of a staged row
+    return row * 256 + ((chunk ^ (row & 15)) << 2);
+}
+
+__global__ void __launch_bounds__(SYMM_THREADS, 2)
+symm_strip_mfma_kernel(const float* __restrict__ Kp, SymLayout L, const float* __restrict__ Vp,
+                       float* __restrict__ Prow, float* __restrict__ Pcol, int64_t max_items,
+                       int64_t total_items) {
+    constexpr int W = 256;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* TB = sm;                              // [2][SM_TR][256]   staged tiles (swizzled)
+    float* VI = TB + 2 * SM_TR * W;              // [2][SM_TR][SMK]   V rows of the tile
+    float* RP = VI + 2 * SM_TR * SMK;            // [2][2][SM_TR][SMK] row parts of the two column halves
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int rb = wave & 1, half = wave >> 1;   // row part: 16 rows x 128 columns per wave
+    int64_t t = 0, before = 0;
+    for (int64_t id = blockIdx.x; id < total_items; id += gridDim.x) {
+        for (;;) {
+            const int64_t cnt = (L.rows(t) + ITEM_ROWS - 1) / ITEM_ROWS;
+            if (id < before + cnt) break;
+            before += cnt;
+            ++t;
+        }
+        const int64_t chunk = id - before;
+        const int64_t nrows = uniform64(L.rows(t));
+        const int64_t item_lo = uniform64(chunk * ITEM_ROWS);
+        const int64_t item_hi = item_lo + ITEM_ROWS < nrows ? item_lo + ITEM_ROWS : nrows;
+        const int64_t diag_lo = uniform64(L.strip(t) * W);
+        const float* base = Kp + uniform64(L.row_offset(t) * W);
+        const int ntile = (int)((item_hi - item_lo + SM_TR - 1) / SM_TR);
+
+        // B operands of the row part: V[diag_lo + 128 half + 16 s + 4 lq + q][rhs = lr]
+        float vB[8][4];
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                vB[s][q] = Vp[(diag_lo + 128 * half + 16 * s + 4 * lq + q) * SMK + lr];
+        sm_acc ccol[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ccol[q][v] = 0.f;
+
+        // staging: per load instruction a wave fetches one whole stored row (1 KiB)
+        float4 pre[8], vpre;
+        auto load_tile = [&](int tl) {
+            const int64_t r0 = item_lo + (int64_t)tl * SM_TR;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t i = r0 + wave + 4 * u;
+                const int64_t ic = i < nrows ? i : nrows - 1;
+                const float4 x = load_stream_at<float4>(base + ic * W, (unsigned)lane * 16u);
+                const float m = i < item_hi ? 1.f : 0.f;  // rows past the item: exact zeros
+                pre[u] = make_float4(x.x * m, x.y * m, x.z * m, x.w * m);
+            }
+            const int64_t iv = r0 + ((tid >> 2) & (SM_TR - 1));
+            vpre = *reinterpret_cast<const float4*>(Vp + (iv < nrows ? iv : nrows - 1) * SMK + (tid & 3) * 4);
+        };
+        auto store_tile = [&](int buf) {
+            float* tb = TB + buf * SM_TR * W;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                *reinterpret_cast<float4*>(tb + sm_at(wave + 4 * u, lane)) = pre[u];
+            if (tid < 4 * SM_TR)
+                *reinterpret_cast<float4*>(VI + buf * SM_TR * SMK + (tid >> 2) * SMK + (tid & 3) * 4) = vpre;
+        };
+        auto flush_rows = [&](int buf, int tl) {  // add the two column halves, store to the row table
+            const float* rp = RP + buf * 2 * SM_TR * SMK;
+            float* pr = Prow + (L.row_offset(t) + item_lo + (int64_t)tl * SM_TR) * SMK;
+            const int64_t live = (item_hi - item_lo - (int64_t)tl * SM_TR) * SMK;
+#pragma unroll
+            for (int e = tid; e < SM_TR * SMK; e += SYMM_THREADS)
+                if (e < live) __builtin_nontemporal_store(rp[e] + rp[SM_TR * SMK + e], &pr[e]);
+        };
+
+        load_tile(0);
+        store_tile(0);
+        load_tile(ntile > 1 ? 1 : 0);
+        __syncthreads();
+        for (int tl = 0; tl < ntile; ++tl) {
+            const int buf = tl & 1;
+            store_tile(buf ^ 1);
+            load_tile(tl + 2 < ntile ? tl + 2 : ntile - 1);
+            if (tl > 0) flush_rows(buf ^ 1, tl - 1);  // (RP[buf ^ 1] was completed before the last barrier)
+            const float* tb = TB + buf * SM_TR * W;
+            // ---- row part ---------------------------------------------------------------------
+            sm_acc crow = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const float4 a = *reinterpret_cast<const float4*>(tb + sm_at(16 * rb + lr, 32 * half + 4 * s + lq));
+                crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, vB[s][0], crow, 0, 0, 0);
+                crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, vB[s][1], crow, 0, 0, 0);
+                crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, vB[s][2], crow, 0, 0, 0);
+                crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, vB[s][3], crow, 0, 0, 0);
+            }
+            float* rp = RP + (buf * 2 + half) * SM_TR * SMK;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) rp[(16 * rb + 4 * lq + v) * SMK + lr] = crow[v];
+            // ---- column part (rows above the diagonal block only; tile-uniform) ----------------
+            if (item_lo + (int64_t)tl * SM_TR < diag_lo) {
+                const float* vi = VI + buf * SM_TR * SMK;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const float4 a = *reinterpret_cast<const float4*>(tb + sm_at(4 * s + lq, 16 * wave + lr));
+                    const float b = vi[(4 * s + lq) * SMK + lr];
+                    ccol[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b, ccol[0], 0, 0, 0);
+                    ccol[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b, ccol[1], 0, 0, 0);
+                    ccol[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b, ccol[2], 0, 0, 0);
+                    ccol[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b, ccol[3], 0, 0, 0);
+                }
+            }
+            __syncthreads();  // tile tl + 1 staged, RP[buf] complete, everyone done with TB[buf]
+        }
+        flush_rows((ntile - 1) & 1, ntile - 1);
+        // column sums of the item: ccol[q][v] = Ycol[column 64 w + 4 (4 lq + v) + q][rhs = lr]
+        float* pc = Pcol + ((t * max_items + chunk) * W) * SMK;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                __builtin_nontemporal_store(ccol[q][v], &pc[(64 * wave + 4 * (4 * lq + v) + q) * SMK + lr]);
+        __syncthreads();  // RP / TB are reused by the next item
+    }
+}
+
 // Y[i][c] = alpha * (row parts of every local strip that stores row i
 //                    + column parts of the local strip that owns column i) + shift * V[i][c]
 // 64 outputs x 16 slices per workgroup: slice y adds the terms y, y + 16, ... (row parts first,
 // then column parts, one combined index); slices are combined in a fixed order through LDS.
 template <typename T>
 __global__ void __launch_bounds__(1024)
-symm_finish_kernel(SymLayout L, int K, const T* __restrict__ Prow, const T* __restrict__ Pcol,
+symm_finish_kernel(SymLayout L, int K, int KT, const T* __restrict__ Prow, const T* __restrict__ Pcol,
                    int64_t max_items, T alpha, T shift, const T* __restrict__ V, int64_t ldv,
-                   T* __restrict__ Y, int64_t ldy) {
+                   T* __restrict__ Y, int64_t ldy) {  // KT: entries per table row (>= K)
     constexpr int NS = 16;
     __shared__ T red[NS][64];
     const int W = L.W;
@@ -318,8 +481,8 @@ symm_finish_kernel(SymLayout L, int K, const T* __restrict__ Prow, const T* __re
         const int64_t jloc = i - blk * W;
         // four independent chains (the loads are latency-bound), combined in a fixed order
         auto term = [&](int64_t u) -> T {
-            return u < nrow ? Prow[(L.row_offset(t0 + u) + i) * K + c]
-                            : Pcol[((tc * max_items + (u - nrow)) * W + jloc) * K + c];
+            return u < nrow ? Prow[(L.row_offset(t0 + u) + i) * KT + c]
+                            : Pcol[((tc * max_items + (u - nrow)) * W + jloc) * KT + c];
         };
         T s4[4] = {T(0), T(0), T(0), T(0)};
         int64_t u = ty;
@@ -440,7 +603,62 @@ static int symm_matmat_impl(const TS* Kp, int64_t n, int64_t first, int64_t stri
         if (rc != RK_OK) return rc;
     }
     hipLaunchKernelGGL((symm_finish_kernel<T>), dim3((unsigned)ceil_div(n * k, 64)), dim3(1024), 0,
-                       st, L, (int)k, Prow, Pcol, max_items, (T)alpha, (T)shift, V, ldv, Y, ldy);
+                       st, L, (int)k, (int)k, Prow, Pcol, max_items, (T)alpha, (T)shift, V, ldv, Y, ldy);
+    return launch_status("rk_symm_matmat(finish)");
+}
+
+// ---- 5 <= k <= 16 right-hand sides (float32): the matrix-core strip kernel ---------------------------
+static size_t symm_wide_ws_bytes(int64_t n, int64_t first, int64_t stride) {
+    const SymLayout L = make_layout<float>(n, first, stride);
+    const int64_t max_items = ceil_div(n, ITEM_ROWS);
+    const size_t vp = (size_t)round_up(n, 256) * SMK;
+    const size_t prow = (size_t)L.total_rows() * SMK;
+    const size_t pcol = (size_t)L.strips_local() * max_items * L.W * SMK;
+    return (vp + prow + pcol) * sizeof(float);
+}
+
+static int symm_matmat_wide_impl(const float* Kp, int64_t n, int64_t first, int64_t stride, const float* V,
+                                 int64_t k, int64_t ldv, double alpha, double shift, float* Y, int64_t ldy,
+                                 void* ws, size_t ws_bytes, hipStream_t st) {
+    const SymLayout L = make_layout<float>(n, first, stride);
+    const int64_t T_loc = L.strips_local();
+    const int64_t max_items = ceil_div(n, ITEM_ROWS);
+    const size_t need = symm_wide_ws_bytes(n, first, stride);
+    if (ws == nullptr || ws_bytes < need) {
+        set_error("rk_symm_matmat: workspace %zu B < required %zu B", ws_bytes, need);
+        return RK_ERR_WORKSPACE;
+    }
+    const int64_t npad = round_up(n, 256);
+    float* Vp = static_cast<float*>(ws);
+    float* Prow = Vp + (size_t)npad * SMK;
+    float* Pcol = Prow + (size_t)L.total_rows() * SMK;
+    hipLaunchKernelGGL(symm_pad_v_kernel, dim3((unsigned)ceil_div(npad * SMK, 256)), dim3(256), 0, st, V, n, npad,
+                       (int)k, ldv, Vp);
+    if (T_loc > 0) {
+        int64_t total_items = 0;
+        for (int64_t t = 0; t < T_loc; ++t) total_items += ceil_div(L.rows(t), ITEM_ROWS);
+        static std::atomic<unsigned long long> attr_devs{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(symm_strip_mfma_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM_SMEM_BYTES) != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("rk_symm_matmat: cannot reserve %zu bytes of LDS", SM_SMEM_BYTES);
+                return RK_ERR_LAUNCH;
+            }
+            attr_devs.fetch_or(bit, std::memory_order_release);
+        }
+        const int64_t resident = symm_resident_workgroups(symm_strip_mfma_kernel, 2);
+        dim3 grid((unsigned)(total_items < resident ? total_items : resident));
+        hipLaunchKernelGGL(symm_strip_mfma_kernel, grid, dim3(SYMM_THREADS), SM_SMEM_BYTES, st, Kp, L, Vp, Prow,
+                           Pcol, max_items, total_items);
+        int rc = launch_status("rk_symm_matmat(wide)");
+        if (rc != RK_OK) return rc;
+    }
+    hipLaunchKernelGGL((symm_finish_kernel<float>), dim3((unsigned)ceil_div(n * k, 64)), dim3(1024), 0, st, L,
+                       (int)k, SMK, Prow, Pcol, max_items, (float)alpha, (float)shift, V, ldv, Y, ldy);
     return launch_status("rk_symm_matmat(finish)");
 }
 
@@ -495,8 +713,10 @@ extern "C" int rk_kernel_materialize_sympack(int dtype, int store_dtype, int kin
 
 extern "C" size_t rk_symm_matmat_ws_bytes(int dtype, int store_dtype, int64_t n, int64_t k,
                                           int64_t strip_first, int64_t strip_stride) {
-    if (n <= 0 || k < 1 || k > 4 || strip_stride < 1 || strip_first < 0 || strip_first >= strip_stride)
-        return 0;
+    if (n <= 0 || k < 1 || strip_stride < 1 || strip_first < 0 || strip_first >= strip_stride) return 0;
+    if (k > 4)
+        return (k <= SMK && dtype == RK_F32 && store_dtype == RK_F32)
+                   ? symm_wide_ws_bytes(n, strip_first, strip_stride) : 0;
     if (dtype == RK_F32) return symm_ws_bytes<float, float>(n, k, strip_first, strip_stride);
     return store_dtype == RK_F32 ? symm_ws_bytes<float, double>(n, k, strip_first, strip_stride)
                                  : symm_ws_bytes<double, double>(n, k, strip_first, strip_stride);
@@ -510,11 +730,16 @@ extern "C" int rk_symm_matmat(int dtype, int store_dtype, const void* Kp, int64_
     int rc = check_layout("rk_symm_matmat", dtype, store_dtype, n, strip_first, strip_stride);
     if (rc != RK_OK) return rc;
     RK_REQUIRE(Kp && V && Y, "rk_symm_matmat: null pointer");
-    RK_REQUIRE(k >= 1 && k <= 4, "rk_symm_matmat: k=%lld outside [1,4]", (long long)k);
+    const bool wide_ok = dtype == RK_F32 && store_dtype == RK_F32;
+    RK_REQUIRE(k >= 1 && k <= (wide_ok ? SMK : 4), "rk_symm_matmat: k=%lld outside [1,%d]", (long long)k,
+               wide_ok ? SMK : 4);
     RK_REQUIRE(ldv >= k && ldy >= k, "rk_symm_matmat: leading dimension too small");
     RK_REQUIRE(aligned16(Kp), "rk_symm_matmat: packed matrix must be 16-byte aligned");
     RK_REQUIRE(aligned16(ws), "rk_symm_matmat: workspace must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (k > 4)
+        return symm_matmat_wide_impl((const float*)Kp, n, strip_first, strip_stride, (const float*)V, k, ldv,
+                                     alpha, diag_shift, (float*)Y, ldy, ws, ws_bytes, st);
     if (dtype == RK_F32)
         return symm_matmat_impl<float, float>((const float*)Kp, n, strip_first, strip_stride,
                                               (const float*)V, k, ldv, alpha, diag_shift, (float*)Y,

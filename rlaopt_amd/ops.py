@@ -13,6 +13,7 @@ package ever does so by itself.
 from __future__ import annotations
 
 import contextlib
+import os
 
 import torch
 
@@ -264,8 +265,12 @@ class HipBackend:
         k = V2.shape[1]
         out = torch.empty((n, k), dtype=V2.dtype, device=dev)
         es = V2.element_size()
-        for c0 in range(0, k, 4):
-            kc = min(4, k - c0)
+        # float32: 5 .. 16 right-hand sides go through the matrix-core strip kernel in ONE pass over the
+        # packed triangle; otherwise groups of 4 (register kernel)
+        group = 16 if (k > 4 and V2.dtype == torch.float32 and Kp.dtype == torch.float32
+                       and os.environ.get("RK_SYMM_WIDE", "1") != "0") else 4
+        for c0 in range(0, k, group):
+            kc = min(group, k - c0)
             ws, wsn = self._workspace(
                 dev, self._lib.rk_symm_matmat_ws_bytes(_dt(V2), _dt(Kp), n, kc, first, stride)
             )

@@ -228,7 +228,7 @@ def test_bad_arguments_raise(be):
 
 @pytest.mark.parametrize("kind", ["rbf", "matern32"])
 @pytest.mark.parametrize("n", [1, 63, 256, 257, 700, 1024, 1025, 3000])
-@pytest.mark.parametrize("k", [1, 2, 3, 4, 7])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 7, 10, 16])
 def test_sympack_product_matches_dense(be, prec, kind, n, k):
     """Strip-packed symmetric storage: y = K v from half the bytes equals the dense product, for
     every strip distribution (first, stride) - partial sums of the ranks add up to K v."""

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Strip-packed symmetric product ``rk_symm_matmat`` for 1 .. 16 right-hand sides on one MI355X:
+ms per product and GB/s of packed bytes; 5 <= k <= 16 with the matrix-core strip kernel (one pass)
+against groups of 4 through the register kernel (RK_SYMM_WIDE=0)."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from rlaopt_amd.ops import get_backend
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=200_000)
+    ap.add_argument("--d", type=int, default=64)
+    ap.add_argument("--ks", default="1,4,5,8,10,16")
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    be = get_backend()
+    n, d = args.n, args.d
+    g = torch.Generator().manual_seed(0)
+    X = (torch.randn(n, d, dtype=torch.float64, generator=g) / d**0.5).float().to(dev)
+    Kp = be.sympack_materialize("rbf", X, 1.0)
+    nbytes = Kp.numel() * 4
+    for k in [int(v) for v in args.ks.split(",")]:
+        V = torch.randn(n, k, dtype=torch.float64, generator=g).float().to(dev)
+        rec = {"n": n, "k": k, "packed_GB": round(nbytes / 1e9, 2)}
+        outs = {}
+        for mode in (["wide", "groups_of_4"] if k > 4 else ["register"]):
+            os.environ["RK_SYMM_WIDE"] = "0" if mode == "groups_of_4" else "1"
+            Y = be.symm_matmat(Kp, n, V)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.reps):
+                be.symm_matmat(Kp, n, V)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.reps
+            outs[mode] = Y
+            rec[mode] = {"ms": round(ms, 3), "packed_GBps_per_pass": round(nbytes / ms / 1e6, 1)}
+        os.environ["RK_SYMM_WIDE"] = "1"
+        if len(outs) == 2:
+            a, b = outs["wide"].double(), outs["groups_of_4"].double()
+            rec["rel_diff_wide_vs_groups"] = float((a - b).norm() / b.norm())
+        print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    main()
