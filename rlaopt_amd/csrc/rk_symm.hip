@@ -17,6 +17,7 @@
 // (bitwise reproducible, no atomics) and applies alpha and the "+ reg v" term.
 // HBM traffic: the packed triangle once (+ ~1 % of partial tables) instead of the full square.
 #include <atomic>
+#include <stdlib.h>
 
 #include "rk_common.h"
 #include "rk_kerneltile.h"
@@ -305,8 +306,10 @@ symm_strip_kernel(const TS* __restrict__ Kp, SymLayout L, const T* __restrict__ 
 // rows x one chunk, one row x 16 chunks) are bank-conflict free.  V is first copied into a zero-
 // padded [round_up(n, 256)][16] array so that every operand load is an aligned, unconditional one.
 constexpr int SMK = 16;                        // right-hand sides carried (k is padded up to it)
-constexpr int SM_TR = 32;                      // rows per tile
-constexpr size_t SM_SMEM_BYTES = (2 * SM_TR * 256 + 2 * SM_TR * SMK + 2 * 2 * SM_TR * SMK) * sizeof(float);
+template <int TR>
+constexpr size_t sm_smem_bytes() {  // staged tiles + V rows of the tile + row parts of the column slices
+    return (size_t)(2 * TR * 256 + 2 * TR * SMK + 2 * (4 / (TR / 16)) * TR * SMK) * sizeof(float);
+}
 
 typedef float sm_acc __attribute__((ext_vector_type(4)));
 
@@ -323,20 +326,28 @@ __device__ __forceinline__ int sm_at(int row, int chunk) {  // float index of 16
     return row * 256 + ((chunk ^ (row & 15)) << 2);
 }
 
-__global__ void __launch_bounds__(SYMM_THREADS, 2)
+// TR = rows per tile: 32 (76 KiB of LDS, 2 workgroups per CU; row part split 2 row blocks x 2 column
+// halves over the waves) or 16 (38 KiB, 4 workgroups per CU; 1 row block x 4 column quarters)
+template <int TR>
+__global__ void __launch_bounds__(SYMM_THREADS, (TR == 32 ? 2 : 4))
 symm_strip_mfma_kernel(const float* __restrict__ Kp, SymLayout L, const float* __restrict__ Vp,
                        float* __restrict__ Prow, float* __restrict__ Pcol, int64_t max_items,
                        int64_t total_items) {
     constexpr int W = 256;
+    constexpr int NRB = TR / 16;          // 16-row blocks per tile
+    constexpr int NCS = 4 / NRB;          // column slices of the row part (one per wave and row block)
+    constexpr int CSW = W / NCS;          // columns per slice: 128 or 64
+    constexpr int NS = CSW / 16;          // 16-column steps per slice: 8 or 4
+    constexpr int RPW = TR / 4;           // staged rows per wave
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* TB = sm;                              // [2][SM_TR][256]   staged tiles (swizzled)
-    float* VI = TB + 2 * SM_TR * W;              // [2][SM_TR][SMK]   V rows of the tile
-    float* RP = VI + 2 * SM_TR * SMK;            // [2][2][SM_TR][SMK] row parts of the two column halves
+    float* TB = sm;                              // [2][TR][256]        staged tiles (swizzled)
+    float* VI = TB + 2 * TR * W;                 // [2][TR][SMK]        V rows of the tile
+    float* RP = VI + 2 * TR * SMK;               // [2][NCS][TR][SMK]   row parts of the column slices
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
-    const int rb = wave & 1, half = wave >> 1;   // row part: 16 rows x 128 columns per wave
+    const int rb = wave % NRB, cs = wave / NRB;  // row part: 16 rows x CSW columns per wave
     int64_t t = 0, before = 0;
     for (int64_t id = blockIdx.x; id < total_items; id += gridDim.x) {
         for (;;) {
@@ -351,81 +362,81 @@ symm_strip_mfma_kernel(const float* __restrict__ Kp, SymLayout L, const float* _
         const int64_t item_hi = item_lo + ITEM_ROWS < nrows ? item_lo + ITEM_ROWS : nrows;
         const int64_t diag_lo = uniform64(L.strip(t) * W);
         const float* base = Kp + uniform64(L.row_offset(t) * W);
-        const int ntile = (int)((item_hi - item_lo + SM_TR - 1) / SM_TR);
+        const int ntile = (int)((item_hi - item_lo + TR - 1) / TR);
 
-        // B operands of the row part: V[diag_lo + 128 half + 16 s + 4 lq + q][rhs = lr]
-        float vB[8][4];
+        // B operands of the row part: V[diag_lo + CSW cs + 16 s + 4 lq + q][rhs = lr]
+        float vB[NS][4];
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
+        for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                vB[s][q] = Vp[(diag_lo + 128 * half + 16 * s + 4 * lq + q) * SMK + lr];
+                vB[s][q] = Vp[(diag_lo + CSW * cs + 16 * s + 4 * lq + q) * SMK + lr];
         sm_acc ccol[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int v = 0; v < 4; ++v) ccol[q][v] = 0.f;
 
-        // staging: per load instruction a wave fetches one whole stored row (1 KiB)
-        float4 pre[8], vpre;
-        auto load_tile = [&](int tl) {
-            const int64_t r0 = item_lo + (int64_t)tl * SM_TR;
+        // staging: per load instruction a wave fetches one whole stored row (1 KiB).  TWO tiles are in
+        // flight per workgroup (register sets A / B, the tile loop is unrolled by two): with one, the
+        // loads of a tile land in the first half of the previous tile's arithmetic and nothing is
+        // outstanding for the rest of it - 32 KiB per CU on average, below what the HBM pipeline
+        // needs (measured: 4.2 TB/s)
+        float4 preA[RPW], preB[RPW], vpreA, vpreB;
+        auto load_tile = [&](int tl, float4 (&pre)[RPW], float4& vpre) {
+            const int64_t r0 = item_lo + (int64_t)(tl < ntile ? tl : ntile - 1) * TR;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < RPW; ++u) {
                 const int64_t i = r0 + wave + 4 * u;
                 const int64_t ic = i < nrows ? i : nrows - 1;
                 const float4 x = load_stream_at<float4>(base + ic * W, (unsigned)lane * 16u);
                 const float m = i < item_hi ? 1.f : 0.f;  // rows past the item: exact zeros
                 pre[u] = make_float4(x.x * m, x.y * m, x.z * m, x.w * m);
             }
-            const int64_t iv = r0 + ((tid >> 2) & (SM_TR - 1));
+            const int64_t iv = r0 + ((tid >> 2) & (TR - 1));
             vpre = *reinterpret_cast<const float4*>(Vp + (iv < nrows ? iv : nrows - 1) * SMK + (tid & 3) * 4);
         };
-        auto store_tile = [&](int buf) {
-            float* tb = TB + buf * SM_TR * W;
+        auto store_tile = [&](int buf, const float4 (&pre)[RPW], const float4& vpre) {
+            float* tb = TB + buf * TR * W;
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < RPW; ++u)
                 *reinterpret_cast<float4*>(tb + sm_at(wave + 4 * u, lane)) = pre[u];
-            if (tid < 4 * SM_TR)
-                *reinterpret_cast<float4*>(VI + buf * SM_TR * SMK + (tid >> 2) * SMK + (tid & 3) * 4) = vpre;
+            if (tid < 4 * TR)
+                *reinterpret_cast<float4*>(VI + buf * TR * SMK + (tid >> 2) * SMK + (tid & 3) * 4) = vpre;
         };
-        auto flush_rows = [&](int buf, int tl) {  // add the two column halves, store to the row table
-            const float* rp = RP + buf * 2 * SM_TR * SMK;
-            float* pr = Prow + (L.row_offset(t) + item_lo + (int64_t)tl * SM_TR) * SMK;
-            const int64_t live = (item_hi - item_lo - (int64_t)tl * SM_TR) * SMK;
+        auto flush_rows = [&](int buf, int tl) {  // add the column slices, store to the row table
+            const float* rp = RP + buf * NCS * TR * SMK;
+            float* pr = Prow + (L.row_offset(t) + item_lo + (int64_t)tl * TR) * SMK;
+            const int64_t live = (item_hi - item_lo - (int64_t)tl * TR) * SMK;
 #pragma unroll
-            for (int e = tid; e < SM_TR * SMK; e += SYMM_THREADS)
-                if (e < live) __builtin_nontemporal_store(rp[e] + rp[SM_TR * SMK + e], &pr[e]);
+            for (int e = tid; e < TR * SMK; e += SYMM_THREADS) {
+                float sum = rp[e];
+#pragma unroll
+                for (int c = 1; c < NCS; ++c) sum += rp[c * TR * SMK + e];
+                if (e < live) __builtin_nontemporal_store(sum, &pr[e]);
+            }
         };
-
-        load_tile(0);
-        store_tile(0);
-        load_tile(ntile > 1 ? 1 : 0);
-        __syncthreads();
-        for (int tl = 0; tl < ntile; ++tl) {
-            const int buf = tl & 1;
-            store_tile(buf ^ 1);
-            load_tile(tl + 2 < ntile ? tl + 2 : ntile - 1);
+        auto compute = [&](int buf, int tl) {
             if (tl > 0) flush_rows(buf ^ 1, tl - 1);  // (RP[buf ^ 1] was completed before the last barrier)
-            const float* tb = TB + buf * SM_TR * W;
+            const float* tb = TB + buf * TR * W;
             // ---- row part ---------------------------------------------------------------------
             sm_acc crow = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const float4 a = *reinterpret_cast<const float4*>(tb + sm_at(16 * rb + lr, 32 * half + 4 * s + lq));
+            for (int s = 0; s < NS; ++s) {
+                const float4 a = *reinterpret_cast<const float4*>(tb + sm_at(16 * rb + lr, (CSW / 4) * cs + 4 * s + lq));
                 crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, vB[s][0], crow, 0, 0, 0);
                 crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, vB[s][1], crow, 0, 0, 0);
                 crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, vB[s][2], crow, 0, 0, 0);
                 crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, vB[s][3], crow, 0, 0, 0);
             }
-            float* rp = RP + (buf * 2 + half) * SM_TR * SMK;
+            float* rp = RP + (buf * NCS + cs) * TR * SMK;
 #pragma unroll
             for (int v = 0; v < 4; ++v) rp[(16 * rb + 4 * lq + v) * SMK + lr] = crow[v];
             // ---- column part (rows above the diagonal block only; tile-uniform) ----------------
-            if (item_lo + (int64_t)tl * SM_TR < diag_lo) {
-                const float* vi = VI + buf * SM_TR * SMK;
+            if (item_lo + (int64_t)tl * TR < diag_lo) {
+                const float* vi = VI + buf * TR * SMK;
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
+                for (int s = 0; s < TR / 4; ++s) {
                     const float4 a = *reinterpret_cast<const float4*>(tb + sm_at(4 * s + lq, 16 * wave + lr));
                     const float b = vi[(4 * s + lq) * SMK + lr];
                     ccol[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b, ccol[0], 0, 0, 0);
@@ -434,7 +445,24 @@ symm_strip_mfma_kernel(const float* __restrict__ Kp, SymLayout L, const float* _
                     ccol[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b, ccol[3], 0, 0, 0);
                 }
             }
-            __syncthreads();  // tile tl + 1 staged, RP[buf] complete, everyone done with TB[buf]
+        };
+
+        load_tile(0, preA, vpreA);
+        store_tile(0, preA, vpreA);
+        load_tile(1, preA, vpreA);
+        load_tile(2, preB, vpreB);
+        __syncthreads();
+        for (int tl = 0; tl < ntile; tl += 2) {
+            store_tile(1, preA, vpreA);        // tile tl + 1
+            load_tile(tl + 3, preA, vpreA);
+            compute(0, tl);
+            __syncthreads();  // tile tl + 1 staged, RP[0] complete, everyone done with TB[0]
+            if (tl + 1 < ntile) {
+                store_tile(0, preB, vpreB);    // tile tl + 2
+                load_tile(tl + 4, preB, vpreB);
+                compute(1, tl + 1);
+                __syncthreads();
+            }
         }
         flush_rows((ntile - 1) & 1, ntile - 1);
         // column sums of the item: ccol[q][v] = Ycol[column 64 w + 4 (4 lq + v) + q][rhs = lr]
@@ -608,6 +636,30 @@ static int symm_matmat_impl(const TS* Kp, int64_t n, int64_t first, int64_t stri
 }
 
 // ---- 5 <= k <= 16 right-hand sides (float32): the matrix-core strip kernel ---------------------------
+template <int TR>
+static int launch_symm_mfma(const float* Kp, const SymLayout& L, const float* Vp, float* Prow, float* Pcol,
+                            int64_t max_items, int64_t total_items, hipStream_t st) {
+    constexpr size_t smem = sm_smem_bytes<TR>();
+    static std::atomic<unsigned long long> attr_devs{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (smem > 65536 && !(attr_devs.load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(symm_strip_mfma_kernel<TR>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("rk_symm_matmat: cannot reserve %zu bytes of LDS", smem);
+            return RK_ERR_LAUNCH;
+        }
+        attr_devs.fetch_or(bit, std::memory_order_release);
+    }
+    const int64_t resident = symm_resident_workgroups(symm_strip_mfma_kernel<TR>, TR == 32 ? 2 : 4);
+    dim3 grid((unsigned)(total_items < resident ? total_items : resident));
+    hipLaunchKernelGGL((symm_strip_mfma_kernel<TR>), grid, dim3(SYMM_THREADS), smem, st, Kp, L, Vp, Prow, Pcol,
+                       max_items, total_items);
+    return RK_OK;
+}
+
 static size_t symm_wide_ws_bytes(int64_t n, int64_t first, int64_t stride) {
     const SymLayout L = make_layout<float>(n, first, stride);
     const int64_t max_items = ceil_div(n, ITEM_ROWS);
@@ -637,23 +689,13 @@ static int symm_matmat_wide_impl(const float* Kp, int64_t n, int64_t first, int6
     if (T_loc > 0) {
         int64_t total_items = 0;
         for (int64_t t = 0; t < T_loc; ++t) total_items += ceil_div(L.rows(t), ITEM_ROWS);
-        static std::atomic<unsigned long long> attr_devs{0};
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        const unsigned long long bit = 1ull << (dev & 63);
-        if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(symm_strip_mfma_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)SM_SMEM_BYTES) != hipSuccess) {
-                (void)hipGetLastError();
-                set_error("rk_symm_matmat: cannot reserve %zu bytes of LDS", SM_SMEM_BYTES);
-                return RK_ERR_LAUNCH;
-            }
-            attr_devs.fetch_or(bit, std::memory_order_release);
-        }
-        const int64_t resident = symm_resident_workgroups(symm_strip_mfma_kernel, 2);
-        dim3 grid((unsigned)(total_items < resident ? total_items : resident));
-        hipLaunchKernelGGL(symm_strip_mfma_kernel, grid, dim3(SYMM_THREADS), SM_SMEM_BYTES, st, Kp, L, Vp, Prow,
-                           Pcol, max_items, total_items);
+        // rows per tile: 32 (default; 17.9 ms at n = 200 000, k = 10) or RK_SYMM_TR=16 (4 workgroups per
+        // CU instead of 2: 18.7 ms - the barrier per 16 KiB costs more than the occupancy gains)
+        const char* e = getenv("RK_SYMM_TR");
+        const bool tr16 = e != nullptr && e[0] == '1';
+        int rcl = tr16 ? launch_symm_mfma<16>(Kp, L, Vp, Prow, Pcol, max_items, total_items, st)
+                       : launch_symm_mfma<32>(Kp, L, Vp, Prow, Pcol, max_items, total_items, st);
+        if (rcl != RK_OK) return rcl;
         int rc = launch_status("rk_symm_matmat(wide)");
         if (rc != RK_OK) return rc;
     }

@@ -31,8 +31,9 @@ def main():
         V = torch.randn(n, k, dtype=torch.float64, generator=g).float().to(dev)
         rec = {"n": n, "k": k, "packed_GB": round(nbytes / 1e9, 2)}
         outs = {}
-        for mode in (["wide", "groups_of_4"] if k > 4 else ["register"]):
+        for mode in (["wide", "wide_tr16", "groups_of_4"] if k > 4 else ["register"]):
             os.environ["RK_SYMM_WIDE"] = "0" if mode == "groups_of_4" else "1"
+            os.environ["RK_SYMM_TR"] = "16" if mode == "wide_tr16" else "32"
             Y = be.symm_matmat(Kp, n, V)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -45,7 +46,8 @@ def main():
             outs[mode] = Y
             rec[mode] = {"ms": round(ms, 3), "packed_GBps_per_pass": round(nbytes / ms / 1e6, 1)}
         os.environ["RK_SYMM_WIDE"] = "1"
-        if len(outs) == 2:
+        os.environ.pop("RK_SYMM_TR", None)
+        if len(outs) >= 2:
             a, b = outs["wide"].double(), outs["groups_of_4"].double()
             rec["rel_diff_wide_vs_groups"] = float((a - b).norm() / b.norm())
         print(json.dumps(rec), flush=True)
