@@ -17,6 +17,9 @@
 //   * columns are cut into S segments so that the grid has >= ~20 rounds of resident waves
 //     (tail < 5 %); per-segment partials are summed in a fixed order by a tiny second
 //     kernel, which also applies the epilogue -> bitwise reproducible results.
+#include <atomic>
+#include <stdlib.h>
+
 #include "rk_common.h"
 
 namespace rk {
@@ -271,13 +274,14 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 skinny_nn_finish(const T* __restrict__ part, int S, int64_t m, int K, T alpha, T beta,
                  const T* __restrict__ C, int64_t ldc, T shift, const T* __restrict__ V,
-                 int64_t ldv, int64_t row0, T* __restrict__ Y, int64_t ldy) {
+                 int64_t ldv, int64_t row0, T* __restrict__ Y, int64_t ldy, int KT = 0) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= m * K) return;
     const int64_t i = e / K;
     const int c = (int)(e - i * K);
+    if (KT == 0) KT = K;  // entries per table row (the matrix-core kernel carries 16)
     T s = T(0);
-    for (int t = 0; t < S; ++t) s += part[(int64_t)t * m * K + e];
+    for (int t = 0; t < S; ++t) s += part[((int64_t)t * m + i) * KT + c];
     T y = alpha * s;
     if (beta != T(0)) y += beta * C[i * ldc + c];
     if (shift != T(0)) y += shift * V[(row0 + i) * ldv + c];
@@ -676,8 +680,162 @@ struct NNPlan {
     int64_t seg_cols;  // multiple of the wave step
 };
 
+// ------------------------------------------------------------------------------------------
+// Y = A V for 5 .. 16 right-hand sides (float32) on the fp32 matrix cores
+// ------------------------------------------------------------------------------------------
+// At 16 right-hand sides the vector units cannot keep up with the HBM stream (16 FMAs per loaded
+// element: the LDS-shared kernel above reaches 2.3 TB/s).  Here a workgroup owns 32 rows and walks a
+// column segment in tiles of 256 columns staged in LDS (32 KiB, double-buffered, two tiles in
+// flight in registers, XOR-swizzled 16-byte chunks - the layout of rk_symm.hip's matrix-core strip
+// kernel, whose row part this is); wave (rb, half) multiplies 16 rows x 128 columns per tile with
+// v_mfma_f32_16x16x4_f32, A operands by ds_read_b128 (4 MFMAs per read), B operands (V of those
+// columns) from a re-packed copy of V in which a lane's 32 values per tile are contiguous.  The
+// accumulator lives across the whole segment; the two column halves are added through LDS once.
+constexpr int MM_K = 16;    // right-hand sides carried
+constexpr int MM_TR = 32;   // rows per workgroup
+constexpr size_t MM_SMEM_BYTES = (2 * MM_TR * 256 + 2 * MM_TR * MM_K) * sizeof(float);
+
+typedef float mm_acc __attribute__((ext_vector_type(4)));
+
+// Vq[((T * 2 + half) * 64 + lane) * 32 + 4 s + q] = V[256 T + 128 half + 16 s + 4 (lane / 16) + q][lane % 16]
+__global__ void __launch_bounds__(256)
+mm_pack_v_kernel(const float* __restrict__ V, int64_t n, int64_t ntile, int k, int64_t ldv, float* __restrict__ Vq) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= ntile * 2 * 64 * 32) return;
+    const int sq = (int)(e & 31), lane = (int)((e >> 5) & 63);
+    const int64_t th = e >> 11;  // T * 2 + half
+    const int64_t col = 128 * th + 16 * (sq >> 2) + 4 * (lane >> 4) + (sq & 3);
+    const int c = lane & 15;
+    Vq[e] = (col < n && c < k) ? V[col * ldv + c] : 0.f;
+}
+
+__device__ __forceinline__ int mm_at(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 2); }
+
+__global__ void __launch_bounds__(256, 2)
+skinny_nn_mfma_kernel(const float* __restrict__ A, int64_t m, int64_t n, int64_t lda, const float* __restrict__ Vq,
+                      float* __restrict__ part, int64_t seg_tiles, int64_t ntile) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* TB = sm;                          // [2][32][256]
+    float* RP = TB + 2 * MM_TR * 256;        // [2 halves][32][16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int rb = wave & 1, half = wave >> 1;
+    const int64_t i0 = (int64_t)blockIdx.x * MM_TR;
+    const int64_t t_lo = (int64_t)blockIdx.y * seg_tiles;
+    const int64_t t_hi = t_lo + seg_tiles < ntile ? t_lo + seg_tiles : ntile;
+    if (t_lo >= t_hi) return;
+    const int64_t t_last = t_hi - 1;
+    // this lane's 4 columns inside a tile; tiles past the matrix edge re-read its last 4 columns, masked.
+    // Two tiles are in flight (register sets A / B, loop unrolled by two).  The V operands of a tile
+    // are requested BEFORE its rows and consumed after them (the wait counter is in order: waiting
+    // for a load that was issued after the tile prefetch would drain the prefetch): they ride in
+    // vinA / vinB and move to vs0 / vs1 when their tile is staged.
+    float4 preA[8], preB[8], vinA[8], vinB[8], vs0[8], vs1[8];
+    auto load_tile = [&](int64_t t, float4 (&pre)[8], float4 (&vin)[8]) {
+        t = t < t_hi ? t : t_last;
+        const float4* vq = reinterpret_cast<const float4*>(Vq + ((t * 2 + half) * 64 + lane) * 32);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) vin[s] = vq[s];
+        __builtin_amdgcn_sched_barrier(0);
+        const int64_t col = 256 * t + 4 * lane;
+        const bool in = col < n;  // (n % 4 == 0: a lane's 4 columns are inside or outside together)
+        const int64_t colc = in ? col : n - 4;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = i0 + wave + 4 * u;
+            const int64_t ic = i < m ? i : m - 1;
+            pre[u] = load_stream<float4>(A + ic * lda + colc);  // (masked when staged: no use here)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto store_tile = [&](int buf, int64_t t, const float4 (&pre)[8], const float4 (&vin)[8], float4 (&vs)[8]) {
+        float* tb = TB + buf * MM_TR * 256;
+        t = t < t_hi ? t : t_last;
+        const bool in = 256 * t + 4 * lane < n;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float msk = (in && i0 + wave + 4 * u < m) ? 1.f : 0.f;  // rows / columns past the edge: zeros
+            *reinterpret_cast<float4*>(tb + mm_at(wave + 4 * u, lane)) =
+                make_float4(pre[u].x * msk, pre[u].y * msk, pre[u].z * msk, pre[u].w * msk);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) vs[s] = vin[s];
+    };
+    mm_acc crow = {0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf, const float4 (&vb)[8]) {
+        const float* tb = TB + buf * MM_TR * 256;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(tb + mm_at(16 * rb + lr, 32 * half + 4 * s + lq));
+            crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, vb[s].x, crow, 0, 0, 0);
+            crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, vb[s].y, crow, 0, 0, 0);
+            crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, vb[s].z, crow, 0, 0, 0);
+            crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, vb[s].w, crow, 0, 0, 0);
+        }
+    };
+    load_tile(t_lo, preA, vinA);
+    store_tile(0, t_lo, preA, vinA, vs0);
+    load_tile(t_lo + 1, preA, vinA);
+    load_tile(t_lo + 2, preB, vinB);
+    __syncthreads();
+    for (int64_t t = t_lo; t < t_hi; t += 2) {
+        store_tile(1, t + 1, preA, vinA, vs1);
+        load_tile(t + 3, preA, vinA);
+        compute(0, vs0);
+        __syncthreads();
+        if (t + 1 < t_hi) {
+            store_tile(0, t + 2, preB, vinB, vs0);
+            load_tile(t + 4, preB, vinB);
+            compute(1, vs1);
+            __syncthreads();
+        }
+    }
+    // crow[v] = Y[row 16 rb + 4 lq + v][rhs lr] over this wave's column half: add the halves, store
+    float* rp = RP + half * MM_TR * MM_K;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) rp[(16 * rb + 4 * lq + v) * MM_K + lr] = crow[v];
+    __syncthreads();
+    for (int e = tid; e < MM_TR * MM_K; e += 256) {
+        const int64_t i = i0 + e / MM_K;
+        if (i < m) part[((int64_t)blockIdx.y * m + i) * MM_K + (e % MM_K)] = RP[e] + RP[MM_TR * MM_K + e];
+    }
+}
+
+struct MMPlan {
+    int64_t ntile, S, seg_tiles;
+};
+static MMPlan plan_mm(int64_t m, int64_t n) {
+    MMPlan p;
+    p.ntile = ceil_div(n, 256);
+    const int64_t row_blocks = ceil_div(m, MM_TR);
+    int64_t S = ceil_div(4096, row_blocks);  // 512 workgroups are resident: >= 8 rounds
+    if (S > p.ntile / 8) S = p.ntile / 8;    // >= 8 tiles per workgroup
+    if (S < 1) S = 1;
+    p.seg_tiles = ceil_div(p.ntile, S);
+    p.S = ceil_div(p.ntile, p.seg_tiles);
+    return p;
+}
+static size_t mm_ws_bytes(int64_t m, int64_t n) {
+    const MMPlan p = plan_mm(m, n);
+    return ((size_t)p.ntile * 2 * 64 * 32 + (size_t)p.S * m * MM_K) * sizeof(float);
+}
+static bool mm_enabled() {
+    const char* e = getenv("RK_SKINNY_MFMA");
+    return !(e != nullptr && e[0] == '0');
+}
+
 // k <= 4: register kernel (V slice in registers); k >= 5: LDS-shared V slice
-static int rows_per_wave(int64_t k) { return k <= 2 ? 8 : (k <= 4 ? 4 : (k <= 8 ? 8 : 4)); }
+// smallest k that takes the LDS-shared kernel (RK_SKINNY_LDS_MIN overrides it for experiments)
+static int64_t lds_min_k() {
+    const char* e = getenv("RK_SKINNY_LDS_MIN");
+    const int64_t v = e ? atoll(e) : 0;
+    return (v >= 3 && v <= 5) ? v : 5;
+}
+static int rows_per_wave(int64_t k) {
+    if (k >= lds_min_k()) return k <= 8 ? 8 : 4;
+    return k <= 2 ? 8 : 4;
+}
 
 static NNPlan plan_nn(int dtype, int64_t m, int64_t n, int64_t k) {
     const int64_t step = (dtype == RK_F32) ? 256 : 128;
@@ -712,6 +870,44 @@ static int matmat_skinny_impl(const T* A, int64_t m, int64_t n, int64_t lda, con
                               double shift, int64_t row0, T* Y, int64_t ldy, void* ws,
                               size_t ws_bytes, hipStream_t st, int dtype) {
     constexpr int VW = Vec16<T>::N;
+    if constexpr (sizeof(T) == 4) {
+        // (measured on the 25 000 x 200 000 shard: the LDS-shared VALU kernel streams 6.6 - 6.2 TB/s at
+        // k = 5 .. 8 and 4.9 at k = 10, 2.2 at k = 16; this kernel 5.0 TB/s at any k)
+        if (k >= 10 && aligned16(A) && lda % 4 == 0 && n % 4 == 0 && n >= 256 && mm_enabled()) {
+            const MMPlan q = plan_mm(m, n);
+            const size_t need = mm_ws_bytes(m, n);
+            if (ws == nullptr || ws_bytes < need) {
+                set_error("rk_matmat_skinny: workspace %zu B < required %zu B", ws_bytes, need);
+                return RK_ERR_WORKSPACE;
+            }
+            float* Vq = static_cast<float*>(ws);
+            float* partq = Vq + (size_t)q.ntile * 2 * 64 * 32;
+            hipLaunchKernelGGL(mm_pack_v_kernel, dim3((unsigned)ceil_div(q.ntile * 4096, 256)), dim3(256), 0, st, V, n,
+                               q.ntile, (int)k, ldv, Vq);
+            static std::atomic<unsigned long long> attr_devs{0};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            const unsigned long long bit = 1ull << (dev & 63);
+            if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_nn_mfma_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)MM_SMEM_BYTES) != hipSuccess) {
+                    (void)hipGetLastError();
+                    set_error("rk_matmat_skinny: cannot reserve %zu bytes of LDS", MM_SMEM_BYTES);
+                    return RK_ERR_LAUNCH;
+                }
+                attr_devs.fetch_or(bit, std::memory_order_release);
+            }
+            dim3 gridq((unsigned)ceil_div(m, MM_TR), (unsigned)q.S);
+            hipLaunchKernelGGL(skinny_nn_mfma_kernel, gridq, dim3(256), MM_SMEM_BYTES, st, A, m, n, lda, Vq, partq,
+                               q.seg_tiles, q.ntile);
+            int rcq = launch_status("rk_matmat_skinny(mfma)");
+            if (rcq != RK_OK) return rcq;
+            hipLaunchKernelGGL((skinny_nn_finish<float>), dim3((unsigned)ceil_div(m * k, 256)), dim3(256), 0, st, partq,
+                               (int)q.S, m, (int)k, (float)alpha, (float)beta, C, ldc, (float)shift, V, ldv, row0, Y,
+                               ldy, MM_K);
+            return launch_status("rk_matmat_skinny(finish)");
+        }
+    }
     const NNPlan p = plan_nn(dtype, m, n, k);
     const bool vec = aligned16(A) && aligned16(V) && (lda % VW == 0) && (ldv == k);
     T* part = nullptr;
@@ -736,6 +932,12 @@ static int matmat_skinny_impl(const T* A, int64_t m, int64_t n, int64_t lda, con
                            row0, Y, ldy, vecA);                                                  \
         break;
     const int vecA = aligned16(A) && (lda % VW == 0);
+    if (k >= lds_min_k() && k < 5) {  // (experiment switch: k = 3, 4 through the LDS-shared kernel)
+        switch (k) {
+            RK_NN_LDS_CASE(3, 8) RK_NN_LDS_CASE(4, 8)
+            default: break;
+        }
+    } else
     switch (k) {
         RK_NN_CASE(1, 8) RK_NN_CASE(2, 8) RK_NN_CASE(3, 4) RK_NN_CASE(4, 4)
         RK_NN_LDS_CASE(5, 8) RK_NN_LDS_CASE(6, 8) RK_NN_LDS_CASE(7, 8) RK_NN_LDS_CASE(8, 8)
@@ -1084,7 +1286,12 @@ extern "C" size_t rk_matmat_skinny_ws_bytes(int dtype, int64_t m, int64_t n, int
     if (m <= 0 || n <= 0 || k <= 0 || k > 16) return 0;
     const NNPlan p = plan_nn(dtype, m, n, k);
     const size_t es = dtype == RK_F32 ? 4 : 8;
-    return p.S > 1 ? (size_t)p.S * m * k * es : 0;
+    size_t bytes = p.S > 1 ? (size_t)p.S * m * k * es : 0;
+    if (dtype == RK_F32 && k >= 10 && n >= 256) {  // the matrix-core kernel: re-packed V + partial sums
+        const size_t b = mm_ws_bytes(m, n);
+        if (b > bytes) bytes = b;
+    }
+    return bytes;
 }
 
 extern "C" int rk_matmat_skinny(int dtype, const void* A, int64_t m, int64_t n, int64_t lda,

@@ -401,8 +401,9 @@ symm_strip_mfma_kernel(const float* __restrict__ Kp, SymLayout L, const float* _
 #pragma unroll
             for (int u = 0; u < RPW; ++u)
                 *reinterpret_cast<float4*>(tb + sm_at(wave + 4 * u, lane)) = pre[u];
-            if (tid < 4 * TR)
-                *reinterpret_cast<float4*>(VI + buf * TR * SMK + (tid >> 2) * SMK + (tid & 3) * 4) = vpre;
+            // (every thread stores: threads past 4 TR hold - and rewrite - the values of row (tid / 4) % TR;
+            // a divergent store makes the compiler drain ALL outstanding loads in front of it)
+            *reinterpret_cast<float4*>(VI + buf * TR * SMK + ((tid >> 2) & (TR - 1)) * SMK + (tid & 3) * 4) = vpre;
         };
         auto flush_rows = [&](int buf, int tl) {  // add the column slices, store to the row table
             const float* rp = RP + buf * NCS * TR * SMK;

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Row-major streaming product ``rk_matmat_skinny`` (the p = 8 shard shape 25 000 x 200 000, float32)
+for 1 .. 16 right-hand sides: ms and GB/s; 5 <= k <= 16 with the matrix-core kernel against the
+LDS-shared VALU kernel (RK_SKINNY_MFMA=0)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from rlaopt_amd.ops import get_backend
+
+dev = torch.device("cuda:0")
+be = get_backend()
+m, n = 25_000, 200_000
+A = torch.randn(m, n, device=dev)
+for k in (1, 2, 3, 4, 5, 8, 9, 10, 12, 16):
+    V = torch.randn(n, k, device=dev)
+    rec = {"m": m, "n": n, "k": k}
+    for mode in (["mfma", "valu_lds"] if k >= 10 else (["register", "valu_lds"] if k in (3, 4) else ["default"])):
+        os.environ["RK_SKINNY_MFMA"] = "0" if mode == "valu_lds" else "1"
+        os.environ["RK_SKINNY_LDS_MIN"] = "3" if mode == "valu_lds" else "5"
+        be.matmat(A, V)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            be.matmat(A, V)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        rec[mode] = {"ms": round(ms, 3), "GBps": round((m * n + n * k + m * k) * 4 / ms / 1e6, 1)}
+    os.environ["RK_SKINNY_MFMA"] = "1"
+    os.environ["RK_SKINNY_LDS_MIN"] = "5"
+    print(json.dumps(rec), flush=True)
