@@ -75,6 +75,11 @@ int rk_kernel_materialize(int dtype, int kind,
  * call with (X1, idx1) and (X2, idx2) exchanged.  n1 / n2 count the LOGICAL points (the
  * idx lengths when idx is given).  If `accumulate` != 0, Y += result. */
 size_t rk_kernel_matmat_ws_bytes(int dtype, int64_t n1, int64_t n2, int64_t k);
+/* Symmetric operands - X1 == X2 (same pointer, same ldx), idx1 == idx2, float32, k <= 4, d <= 64, a
+ * gram_center: with a workspace of at least max(rk_kernel_matmat_ws_bytes, this) bytes the product
+ * evaluates only the tiles on and above the diagonal and uses each for y[i] += P v[j] and
+ * y[j] += P^T v[i] (half the matrix-core and exponential work; fixed summation order). */
+size_t rk_kernel_matmat_sym_ws_bytes(int dtype, int64_t n, int64_t k);
 int rk_kernel_matmat(int dtype, int kind,
                      const void* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
                      const void* X2, int64_t n2, int64_t ldx2, const int64_t* idx2,

@@ -109,35 +109,57 @@ gram_split_kernel(const float* __restrict__ X, int64_t ldx, const int64_t* __res
 }
 
 constexpr size_t BX_SMEM_BYTES = 2 * BX_IMG + 2 * BX_VROWS * BX_LDV * sizeof(float) + 2 * BX_VROWS * sizeof(float);
+constexpr size_t bx_sym_smem_bytes(int kv) {  // + column sums [2][4 waves][64][kv] + 64 dummy slots
+    return BX_SMEM_BYTES + (size_t)(2 * 4 * 64 * kv + 64) * sizeof(float);
+}
 
 // KV = 0: second product on the float32 matrix cores (k <= 16); KV = 1 / 2 / 4: on the VALU (k <= KV)
 // NKS = k-steps of 32 features (1: d <= 32, 2: d <= 64, 4: d <= 128 - half-height tiles)
 // (A hand-ordered instruction stream - operand reads one step ahead, kappa of block row jb - 1 placed in
 // the shadow of the MFMAs of block row jb with sched_barrier - was 3 - 11 % SLOWER than the compiler's
 // order: two workgroups per CU already overlap one wave's kappa with the other's MFMAs.)
-template <bool RBF, int KV, int NKS>
+// SYM (X1 is X2, k <= 4): only the tiles on and above the diagonal are evaluated; a tile beyond the
+// diagonal 128 x 128 block feeds y[i] += P v[j] AND y[j] += P^T v[i] (the column sums of the tile:
+// per lane 2 FMAs and a 16-lane DPP reduction per row of P, added over the 4 waves through LDS and
+// written to a (work item, tile) table).  Work items (row block, tile segment) are listed by
+// bx_sym_items_kernel; a finishing kernel adds, in a fixed order, the row parts of a row block's
+// items and the column parts of every row block above.  Half the matrix-core and exponential work.
+struct BxSym {
+    const int* item_rb;        // row block of an item
+    const int64_t* item_tlo;   // its first tile
+    const int64_t* item_coff;  // tiles before it in the column table
+    int64_t segt;              // tiles per item
+    float* prow;               // [item][128][KV]
+    float* pcol;               // [column-table tile][64][KV]
+};
+
+template <bool RBF, int KV, int NKS, bool SYM>
 __global__ void __launch_bounds__(256, 2)
 kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, const unsigned char* __restrict__ img2,
                           int64_t n1, int64_t n2, float w, float scale, const float* __restrict__ nx,
                           const float* __restrict__ ny, const float* __restrict__ V, int k, int64_t ldv,
                           int64_t tiles_per_seg, float* __restrict__ part, float* __restrict__ Y, int64_t ldy,
-                          int accumulate) {
+                          int accumulate, BxSym sym) {
     using G = BxGeo<(NKS <= 2 ? 64 : 128)>;
     constexpr int TJ = G::TJ;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* XB = smem;                                                  // [2][BX_IMG]
     float* VS = reinterpret_cast<float*>(smem + 2 * BX_IMG);                   // [2][BX_VROWS][BX_LDV]
     float* NY = VS + 2 * BX_VROWS * BX_LDV;                                    // [2][BX_VROWS]
+    float* CS = NY + 2 * BX_VROWS;                                             // SYM: [2][4][64][KV] + dummy slots
     const float rbf_c = -0.5f * w * w * 1.4426950408889634f;  // exp(-s w^2 / 2) = exp2(rbf_c s)
     const float m2c = -2.f * rbf_c;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    const int64_t i0 = (int64_t)blockIdx.x * BX_TI;
     const int64_t ntile = (n2 + TJ - 1) / TJ;
-    const int64_t t_lo = (int64_t)blockIdx.y * tiles_per_seg;
-    const int64_t t_hi = (t_lo + tiles_per_seg < ntile) ? t_lo + tiles_per_seg : ntile;
+    const int64_t rblk = SYM ? (int64_t)sym.item_rb[blockIdx.x] : (int64_t)blockIdx.x;
+    const int64_t i0 = rblk * BX_TI;
+    const int64_t seg_len = SYM ? sym.segt : tiles_per_seg;
+    const int64_t t_lo = SYM ? sym.item_tlo[blockIdx.x] : (int64_t)blockIdx.y * tiles_per_seg;
+    const int64_t t_hi = (t_lo + seg_len < ntile) ? t_lo + seg_len : ntile;
+    const int64_t t_sym = 2 * rblk + 2;  // SYM: tiles from here on lie beyond the diagonal block
 
     // ---- this wave's X1 operands: 2 blocks of 16 points x 2 k-steps x 3 splits, resident ----------
     bx_frag bh[2][NKS], bm[2][NKS], bl[2][NKS];
@@ -157,6 +179,17 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
         // (nx has round_up(n1, 128) entries.)  RBF: the exponent is formed directly in base 2,
         // exp2(rbf_c |x|^2 + rbf_c |y|^2 - 2 rbf_c S): the norms are kept pre-multiplied by rbf_c
         nxr[ib] = nx[ip] * (RBF ? rbf_c : 1.f);
+    }
+
+    constexpr int KVS = (SYM && KV > 0) ? KV : 1;
+    float vi[2][KVS];  // SYM: V of this lane's two X1 points (B side of the column sums)
+    if constexpr (SYM) {
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+            const int64_t ip = i0 + wave * 32 + ib * 16 + lr;
+#pragma unroll
+            for (int c = 0; c < KVS; ++c) vi[ib][c] = (ip < n1 && c < k) ? V[ip * ldv + c] : 0.f;
+        }
     }
 
     // ---- tile staging: registers -> LDS (the image is copied linearly: it is stored swizzled) -------
@@ -213,6 +246,15 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
         // body is one basic block and the scheduler can mix matrix-core and vector work
         store_tile(buf ^ 1);
         load_tile(t + 2 < t_hi ? t + 2 : t_last);
+        if constexpr (SYM) {  // column sums of tile t - 1 (complete since the last barrier): 4 waves -> table
+            if (t > t_lo && t - 1 >= t_sym && tid < 64 * KVS) {
+                const float* cs = CS + (buf ^ 1) * 4 * 64 * KVS;
+                const float sum = ((cs[tid] + cs[64 * KVS + tid]) + cs[2 * 64 * KVS + tid]) + cs[3 * 64 * KVS + tid];
+                __builtin_nontemporal_store(sum, &sym.pcol[(sym.item_coff[blockIdx.x] + (t - 1 - t_lo)) * 64 * KVS + tid]);
+            }
+        }
+        const bool sym_tile = SYM && t >= t_sym;
+        float* csw = CS + (buf * 4 + wave) * 64 * KVS;
         const unsigned char* xb = XB + buf * BX_IMG;
         const float* vsb = VS + buf * BX_VROWS * BX_LDV;
         const float* nyb = NY + buf * BX_VROWS;
@@ -244,6 +286,7 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
             // ---- P = kappa(|x|^2 + |y|^2 - 2 S); Y^T += V^T P^T ------------------------------------
             const float4 ny4 = *reinterpret_cast<const float4*>(nyb + jb * 16 + 4 * lq);
             const float nyv[4] = {ny4.x, ny4.y, ny4.z, ny4.w};
+            float qv[4][KVS];  // SYM: this lane's share p[0] v_i0 + p[1] v_i1 of the column sums of rows v = 0 .. 3
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 float p[2];
@@ -278,6 +321,34 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
                     for (int c = 0; c < KV; ++c)
 #pragma unroll
                         for (int ib = 0; ib < 2; ++ib) yv[ib][c] += p[ib] * vv[c];
+                    if constexpr (SYM) {
+#pragma unroll
+                        for (int c = 0; c < KV; ++c) qv[v][c] = fmaf(p[0], vi[0][c], p[1] * vi[1][c]);
+                    }
+                }
+            }
+            if constexpr (SYM && KV > 0) {
+                if (sym_tile) {  // (tile-uniform)
+                    // 4 values per lane x 16 lanes -> 4 sums: a reduce-scatter butterfly (lane pairs trade
+                    // two of their four values, then one of two) and two in-row rotations: 11 vector
+                    // instructions per right-hand side instead of 16 for four separate 16-lane sums.
+                    // Afterwards lane lr holds the sum of row v = 2 (lr & 1) + ((lr >> 1) & 1).
+                    const bool b0 = lr & 1, b1 = lr & 2;
+#pragma unroll
+                    for (int c = 0; c < KV; ++c) {
+                        const float k0 = b0 ? qv[2][c] : qv[0][c], k1 = b0 ? qv[3][c] : qv[1][c];
+                        const float s0 = b0 ? qv[0][c] : qv[2][c], s1 = b0 ? qv[1][c] : qv[3][c];
+                        const float r0 = k0 + dpp_fetch<0xB1, 0xF>(s0);  // quad_perm [1,0,3,2]: lane ^ 1
+                        const float r1 = k1 + dpp_fetch<0xB1, 0xF>(s1);
+                        const float kk = b1 ? r1 : r0, ss = b1 ? r0 : r1;
+                        float u = kk + dpp_fetch<0x4E, 0xF>(ss);         // quad_perm [2,3,0,1]: lane ^ 2
+                        u += dpp_fetch<0x124, 0xF>(u);                   // row_ror:4
+                        u += dpp_fetch<0x128, 0xF>(u);                   // row_ror:8: every lane, its row's total
+                        // lanes lr < 4 store (the others into dummy slots: one unconditional ds_write)
+                        const int vrow = 2 * (lr & 1) + ((lr >> 1) & 1);
+                        float* dst = lr < 4 ? csw + (jb * 16 + 4 * lq + vrow) * KVS + c : CS + 2 * 4 * 64 * KVS + lane;
+                        *dst = u;
+                    }
                 }
             }
         }
@@ -292,6 +363,13 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
             }
         }
         __syncthreads();  // tile t + 1 is in LDS; every wave is done with tile t's buffer
+    }
+    if constexpr (SYM) {  // column sums of the last tile
+        if (t_last >= t_sym && tid < 64 * KVS) {
+            const float* cs = CS + (int)((t_last - t_lo) & 1) * 4 * 64 * KVS;
+            const float sum = ((cs[tid] + cs[64 * KVS + tid]) + cs[2 * 64 * KVS + tid]) + cs[3 * 64 * KVS + tid];
+            __builtin_nontemporal_store(sum, &sym.pcol[(sym.item_coff[blockIdx.x] + (t_last - t_lo)) * 64 * KVS + tid]);
+        }
     }
     // ---- this wave's 32 rows of Y: through LDS as [i (128)][rhs (16)], then coalesced out ---------------
     float* yl = reinterpret_cast<float*>(XB);  // (all reads of the last tile are behind the barrier above)
@@ -320,6 +398,10 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
             sum = (q.x + q.y) + (q.z + q.w);
         }
         const int64_t i = i0 + il;
+        if constexpr (SYM) {
+            sym.prow[((int64_t)blockIdx.x * BX_TI + il) * KVS + c] = sum;  // (rows past n1 are never read)
+            continue;
+        }
         if (i >= n1) continue;
         if (part != nullptr) {
             part[((int64_t)blockIdx.y * n1 + i) * k + c] = sum;
@@ -329,6 +411,85 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
             else Y[i * ldy + c] = o;
         }
     }
+}
+
+size_t bx_aux_bytes(int64_t n1, int64_t n2);
+
+// ---- symmetric products: work list and finishing kernel ------------------------------------------------
+// Row block rb (128 points) owns the 64-point tiles 2 rb .. T - 1, cut into items of `segt` tiles.
+__global__ void bx_sym_items_kernel(int64_t T, int64_t nrb, int64_t segt, int* __restrict__ item_rb,
+                                    int64_t* __restrict__ item_tlo, int64_t* __restrict__ item_coff,
+                                    int64_t* __restrict__ rb_base) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int64_t items = 0, coff = 0;
+    for (int64_t rb = 0; rb < nrb; ++rb) {
+        rb_base[rb] = items;
+        for (int64_t t = 2 * rb; t < T; t += segt) {
+            item_rb[items] = (int)rb;
+            item_tlo[items] = t;
+            item_coff[items] = coff;
+            coff += (t + segt < T ? segt : T - t);
+            ++items;
+        }
+    }
+    rb_base[nrb] = items;
+}
+static void bx_sym_counts(int64_t n, int64_t segt, int64_t* items, int64_t* col_tiles) {
+    const int64_t T = ceil_div(n, 64), nrb = ceil_div(n, 128);
+    int64_t it = 0, ct = 0;
+    for (int64_t rb = 0; rb < nrb; ++rb) {
+        const int64_t nt = T - 2 * rb;
+        it += ceil_div(nt, segt);
+        ct += nt;
+    }
+    *items = it;
+    *col_tiles = ct;
+}
+static int64_t bx_sym_segt(int64_t n) {
+    const int64_t T = ceil_div(n, 64);
+    int64_t segt = (T * T / 4) / 4096;  // ~4 096 items: 8 rounds of the 512 resident workgroups
+    if (segt < 8) segt = 8;
+    if (segt > 1024) segt = 1024;
+    return segt;
+}
+
+// Y[r][c] = scale * (row parts of the items of r's row block + column parts of every row block above)
+template <int KV>
+__global__ void __launch_bounds__(256)
+bx_sym_finish_kernel(int64_t n, int k, int64_t segt, const int64_t* __restrict__ rb_base,
+                     const int64_t* __restrict__ item_coff, const float* __restrict__ prow,
+                     const float* __restrict__ pcol, float scale, float* __restrict__ Y, int64_t ldy, int accumulate) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * k) return;
+    const int64_t r = e / k;
+    const int c = (int)(e - r * k);
+    const int64_t rb = r >> 7, t = r >> 6;
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t it = rb_base[rb], u = 0; it < rb_base[rb + 1]; ++it, ++u)
+        s4[u & 3] += prow[(it * BX_TI + (r & 127)) * KV + c];
+    const int64_t above = t >= 2 ? (t - 2) / 2 + 1 : 0;  // row blocks rb' with 2 rb' + 2 <= t
+    for (int64_t b = 0; b < above; ++b) {
+        const int64_t rel = t - 2 * b;
+        const int64_t it = rb_base[b] + rel / segt;
+        s4[b & 3] += pcol[((item_coff[it] + rel % segt) * 64 + (r & 63)) * KV + c];
+    }
+    const float o = scale * ((s4[0] + s4[1]) + (s4[2] + s4[3]));
+    if (accumulate) Y[r * ldy + c] += o;
+    else Y[r * ldy + c] = o;
+}
+
+size_t bx_sym_ws_bytes(int64_t n, int64_t k) {
+    if (k < 1 || k > 4) return 0;
+    const int kv = k <= 1 ? 1 : (k <= 2 ? 2 : 4);
+    const int64_t segt = bx_sym_segt(n);
+    int64_t items = 0, col_tiles = 0;
+    bx_sym_counts(n, segt, &items, &col_tiles);
+    const int64_t nrb = ceil_div(n, 128);
+    size_t b = bx_aux_bytes(n, 0);                                   // map, norms, ONE set of images
+    b += (size_t)round_up(items * (int64_t)(sizeof(int) + 2 * sizeof(int64_t)) + (nrb + 1) * (int64_t)sizeof(int64_t), 256);
+    b += (size_t)round_up(items * BX_TI * kv * (int64_t)sizeof(float), 256);
+    b += (size_t)col_tiles * 64 * kv * sizeof(float);
+    return b;
 }
 
 // workspace behind the partial sums: affine map (2 x 128 floats), |x'|^2 of both sets (padded), the
@@ -371,9 +532,9 @@ int launch_kmatmat_bf16x3(int kind, const float* X1, int64_t n1, int64_t ldx1, c
     const int nks = d <= 32 ? 1 : (d <= 64 ? 2 : 4);
     dim3 grid((unsigned)ceil_div(n1, BX_TI), (unsigned)S);
 #define RK_BX_N(RBFV, KVV, NKSV)                                                                           \
-    hipLaunchKernelGGL((kmat_matmat_bf16x3_kernel<RBFV, KVV, NKSV>), grid, dim3(256), BX_SMEM_BYTES, st,   \
-                       kind, img1, img2, n1, n2, w, scale, nxp, nyp, V, k, ldv, tiles_per_seg, part, Y, ldy, \
-                       accumulate)
+    hipLaunchKernelGGL((kmat_matmat_bf16x3_kernel<RBFV, KVV, NKSV, false>), grid, dim3(256), BX_SMEM_BYTES, \
+                       st, kind, img1, img2, n1, n2, w, scale, nxp, nyp, V, k, ldv, tiles_per_seg, part, Y, ldy, \
+                       accumulate, BxSym{})
 #define RK_BX(RBFV, KVV)                                                                                   \
     do {                                                                                                   \
         if (nks == 1) RK_BX_N(RBFV, KVV, 1);                                                               \
@@ -393,6 +554,72 @@ int launch_kmatmat_bf16x3(int kind, const float* X1, int64_t n1, int64_t ldx1, c
 #undef RK_BX_N
 #undef RK_BX_K
     return launch_status("rk_kernel_matmat(bf16x3)");
+}
+
+// Symmetric product (X1 is X2, same gather, k <= 4, d <= 64): `aux` = bx_sym_ws_bytes(n, k) bytes.
+int launch_kmatmat_bf16x3_sym(int kind, const float* X, int64_t n, int64_t ldx, const int64_t* idx, int64_t d,
+                              float w, const float* ell_vec, const float* center, float scale, const float* V,
+                              int k, int64_t ldv, void* aux, float* Y, int64_t ldy, int accumulate, hipStream_t st) {
+    const int kv = k <= 1 ? 1 : (k <= 2 ? 2 : 4);
+    const int64_t segt = bx_sym_segt(n);
+    int64_t items = 0, col_tiles = 0;
+    bx_sym_counts(n, segt, &items, &col_tiles);
+    const int64_t T = ceil_div(n, 64), nrb = ceil_div(n, 128);
+    const int64_t npad = round_up(n, BX_TI);
+    char* base = static_cast<char*>(aux);
+    float* iw = reinterpret_cast<float*>(base);
+    float* muw = iw + 128;
+    float* nrm = muw + 128;
+    unsigned char* img = reinterpret_cast<unsigned char*>(base) + bx_float_bytes(n, 0);
+    char* lists = base + bx_aux_bytes(n, 0);
+    int64_t* item_tlo = reinterpret_cast<int64_t*>(lists);
+    int64_t* item_coff = item_tlo + items;
+    int64_t* rb_base = item_coff + items;
+    int* item_rb = reinterpret_cast<int*>(rb_base + nrb + 1);
+    float* prow = reinterpret_cast<float*>(
+        lists + round_up(items * (int64_t)(sizeof(int) + 2 * sizeof(int64_t)) + (nrb + 1) * (int64_t)sizeof(int64_t), 256));
+    float* pcol = prow + round_up(items * BX_TI * kv * (int64_t)sizeof(float), 256) / sizeof(float);
+    gram_prep_launch(center, ell_vec, d, iw, muw, st);
+    hipLaunchKernelGGL(gram_split_kernel<64>, dim3((unsigned)ceil_div(npad * 8, 256)), dim3(256), 0, st, X, ldx, idx,
+                       n, npad, d, iw, muw, img, nrm);
+    hipLaunchKernelGGL(bx_sym_items_kernel, dim3(1), dim3(1), 0, st, T, nrb, segt, item_rb, item_tlo, item_coff,
+                       rb_base);
+    BxSym sym{item_rb, item_tlo, item_coff, segt, prow, pcol};
+    const int nks = d <= 32 ? 1 : 2;
+    dim3 grid((unsigned)items);
+#define RK_BXS_N(RBFV, KVV, NKSV)                                                                          \
+    hipLaunchKernelGGL((kmat_matmat_bf16x3_kernel<RBFV, KVV, NKSV, true>), grid, dim3(256),               \
+                       bx_sym_smem_bytes(KVV), st, kind, img, img, n, n, w, scale, nrm, nrm, V, k, ldv,    \
+                       (int64_t)0, (float*)nullptr, (float*)nullptr, (int64_t)0, 0, sym)
+#define RK_BXS(RBFV, KVV)                                                                                  \
+    do {                                                                                                   \
+        if (nks == 1) RK_BXS_N(RBFV, KVV, 1);                                                              \
+        else RK_BXS_N(RBFV, KVV, 2);                                                                       \
+    } while (0)
+#define RK_BXS_K(RBFV)                                                                                     \
+    do {                                                                                                   \
+        if (kv == 1) RK_BXS(RBFV, 1);                                                                      \
+        else if (kv == 2) RK_BXS(RBFV, 2);                                                                 \
+        else RK_BXS(RBFV, 4);                                                                              \
+    } while (0)
+    if (kind == RK_RBF) RK_BXS_K(true);
+    else RK_BXS_K(false);
+#undef RK_BXS_K
+#undef RK_BXS
+#undef RK_BXS_N
+    int rc = launch_status("rk_kernel_matmat(bf16x3, symmetric)");
+    if (rc != RK_OK) return rc;
+    const dim3 fg((unsigned)ceil_div(n * k, 256));
+    if (kv == 1)
+        hipLaunchKernelGGL(bx_sym_finish_kernel<1>, fg, dim3(256), 0, st, n, k, segt, rb_base, item_coff, prow, pcol,
+                           scale, Y, ldy, accumulate);
+    else if (kv == 2)
+        hipLaunchKernelGGL(bx_sym_finish_kernel<2>, fg, dim3(256), 0, st, n, k, segt, rb_base, item_coff, prow, pcol,
+                           scale, Y, ldy, accumulate);
+    else
+        hipLaunchKernelGGL(bx_sym_finish_kernel<4>, fg, dim3(256), 0, st, n, k, segt, rb_base, item_coff, prow, pcol,
+                           scale, Y, ldy, accumulate);
+    return launch_status("rk_kernel_matmat(bf16x3, symmetric finish)");
 }
 
 }  // namespace rk

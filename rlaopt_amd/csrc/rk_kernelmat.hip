@@ -671,6 +671,22 @@ int launch_kmatmat_bf16x3(int kind, const float* X1, int64_t n1, int64_t ldx1, c
                           int64_t ldv, int64_t S, int64_t tiles_per_seg, void* aux, float* part, float* Y,
                           int64_t ldy, int accumulate, hipStream_t st);
 
+size_t bx_sym_ws_bytes(int64_t n, int64_t k);
+int launch_kmatmat_bf16x3_sym(int kind, const float* X, int64_t n, int64_t ldx, const int64_t* idx, int64_t d,
+                              float w, const float* ell_vec, const float* center, float scale, const float* V,
+                              int k, int64_t ldv, void* aux, float* Y, int64_t ldy, int accumulate, hipStream_t st);
+// symmetric operands (same points, same gather), k <= 4, d <= 64: half the tiles (RK_KMAT_SYM=0: all)
+static bool kmat_use_sym() {
+    const char* e = getenv("RK_KMAT_SYM");
+    return !(e != nullptr && e[0] == '0');
+}
+
+// (measured, n = 200 000, d = 64: k = 1 18.3 vs 26.1 ms, k = 2 20.0 vs 27.0, k = 4 24.5 vs 29.4; d = 32 does not
+// gain - the column sums are vector work and one k-step leaves little matrix-core time to save -, and below
+// n ~ 65 000 the work list and the finishing kernel cost more than the saved tiles)
+static int64_t sym_max_k() { const char* e = getenv("RK_KMAT_SYM_MAXK"); return e ? atoll(e) : 4; }
+static int64_t sym_min_n() { const char* e = getenv("RK_KMAT_SYM_MINN"); return e ? atoll(e) : 65536; }
+
 static bool kmat_use_bf16x3() {
     const char* e = getenv("RK_KMAT_BF16X3");
     return !(e != nullptr && e[0] == '0');
@@ -716,6 +732,11 @@ static int kmatmat_impl(int kind, const T* X1, int64_t n1, int64_t ldx1, const i
                         size_t ws_bytes, hipStream_t st) {
     const T w = ell_vec ? T(1) : T(1.0 / ell);
     if constexpr (sizeof(T) == 4) {
+        if (kmat_use_gram(kind, gram_center, d, 64, n1, n2) && kmat_use_bf16x3() && kmat_use_sym() && X1 == X2 &&
+            idx1 == idx2 && n1 == n2 && ldx1 == ldx2 && k <= sym_max_k() && d > 32 && n1 >= sym_min_n() && ws != nullptr &&
+            ws_bytes >= bx_sym_ws_bytes(n1, k))
+            return launch_kmatmat_bf16x3_sym(kind, X1, n1, ldx1, idx1, d, (float)w, ell_vec, gram_center,
+                                             (float)scale, V, (int)k, ldv, ws, Y, ldy, accumulate, st);
         if (kmat_use_gram(kind, gram_center, d, 128, n1, n2) && kmat_use_bf16x3()) {
             const KMPlan pb = plan_kmatmat_bf16(n1, n2, bx_tile_points(d));
             const size_t off = kmat_norms_offset(pb.S, n1, k);
@@ -853,6 +874,12 @@ extern "C" size_t rk_kernel_matmat_ws_bytes(int dtype, int64_t n1, int64_t n2, i
         }
     }
     return bytes;
+}
+
+/* workspace that additionally enables the symmetric evaluation (X1 == X2, idx1 == idx2, k <= 4) */
+extern "C" size_t rk_kernel_matmat_sym_ws_bytes(int dtype, int64_t n, int64_t k) {
+    if (dtype != RK_F32 || n < 256 || k < 1 || k > 4) return 0;
+    return bx_sym_ws_bytes(n, k);
 }
 
 extern "C" int rk_kernel_matmat(int dtype, int kind, const void* X1, int64_t n1, int64_t ldx1,

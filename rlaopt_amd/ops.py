@@ -222,9 +222,15 @@ class HipBackend:
         V2, ldv = _rowmajor(V2)
         k = V2.shape[1]
         out = torch.empty((n1, k), dtype=X1.dtype, device=dev)
+        same = (X1.data_ptr() == X2.data_ptr() and ld1 == ld2 and n1 == n2 and gram_center is not None
+                and (idx1 is idx2 or (idx1 is not None and idx2 is not None and idx1.data_ptr() == idx2.data_ptr())))
+        if same and idx1 is not None:
+            idx2 = idx1  # (one pointer: the C side recognises the symmetric case by pointer equality)
         for c0 in range(0, k, MAX_SKINNY):
             kc = min(MAX_SKINNY, k - c0)
             nbytes = self._lib.rk_kernel_matmat_ws_bytes(_dt(X1), n1, n2, kc)
+            if same:  # symmetric evaluation (half the tiles) needs its tables
+                nbytes = max(nbytes, self._lib.rk_kernel_matmat_sym_ws_bytes(_dt(X1), n1, kc))
             ws, wsn = self._workspace(dev, nbytes)
             es = V2.element_size()
             rc = self._lib.rk_kernel_matmat(

@@ -571,3 +571,37 @@ def test_matmat_skinny_matrix_core_kernel(be, monkeypatch, m, n, k):
     assert not torch.equal(got, base)  # two different kernels ran
     assert torch.equal(got, be.matmat(Ad, V.to(dev()), alpha=-1.5, beta=0.25, C=C.to(dev()), diag_shift=shift, row0=row0))
     del nv
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern52"])
+@pytest.mark.parametrize("n,d", [(256, 8), (700, 64), (1000, 33), (2500, 50), (2049, 64)])
+@pytest.mark.parametrize("k", [1, 2, 3, 4])
+def test_kernel_matmat_symmetric_evaluation(be, monkeypatch, kind, n, d, k):
+    """K(X, X) @ V matrix-free with the symmetric evaluation (only the tiles on and above the diagonal,
+    each used for y[i] += P v[j] and y[j] += P^T v[i]) against the oracle and against the full
+    evaluation (RK_KMAT_SYM=0); also through one shared index list (the block oracle K(X[blk], X[blk]))."""
+    dt = torch.float32
+    monkeypatch.setenv("RK_KMAT_SYM_MINN", "1")  # (the product defaults: n >= 65 536, k <= 2)
+    monkeypatch.setenv("RK_KMAT_SYM_MAXK", "4")
+    gen = torch.Generator().manual_seed(n + d + k)
+    X = torch.randn(n, d, dtype=dt, generator=gen) / d**0.5
+    V = torch.randn(n, k, dtype=dt, generator=gen)
+    Xd, Vd = X.to(dev()), V.to(dev())
+    gc = be.gram_center(Xd, Xd, 0.9)
+    assert gc is not None
+    want = ok.kernel_matmat(kind, X.double(), X.double(), 0.9, V.double(), 1.25)
+    got = be.kernel_matmat(kind, Xd, Xd, 0.9, Vd, scale=1.25, gram_center=gc)
+    monkeypatch.setenv("RK_KMAT_SYM", "0")
+    full = be.kernel_matmat(kind, Xd, Xd, 0.9, Vd, scale=1.25, gram_center=gc)
+    monkeypatch.delenv("RK_KMAT_SYM")
+    assert rel_err(got.cpu(), want) < LIM[dt]
+    assert rel_err(got.cpu(), full.cpu().double()) < LIM[dt]
+    assert torch.equal(got, full) == (d <= 32)  # rows longer than 32 features: the symmetric evaluation ran
+    assert torch.equal(got, be.kernel_matmat(kind, Xd, Xd, 0.9, Vd, scale=1.25, gram_center=gc))  # reproducible
+    if n >= 700:
+        blk = torch.randperm(n, generator=gen)[: n // 2 + 3].to(dev())
+        Vb = Vd[: blk.numel()].contiguous()
+        want_b = ok.kernel_matmat(kind, X.double(), X.double(), 0.9, V[: blk.numel()].double(), 1.25,
+                                  idx1=blk.cpu(), idx2=blk.cpu())
+        got_b = be.kernel_matmat(kind, Xd, Xd, 0.9, Vb, scale=1.25, idx1=blk, idx2=blk, gram_center=gc)
+        assert rel_err(got_b.cpu(), want_b) < LIM[dt]

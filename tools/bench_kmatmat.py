@@ -17,12 +17,12 @@ import torch
 
 from rlaopt_amd.ops import get_backend
 
-MODES = {"bf16x3": {}, "mfma32": {"RK_KMAT_BF16X3": "0"},
+MODES = {"bf16x3": {}, "bf16x3_full": {"RK_KMAT_SYM": "0"}, "mfma32": {"RK_KMAT_BF16X3": "0"},
          "direct": {"RK_KMAT_MFMA": "0"}}
 
 
 def set_mode(mode):
-    for key in ("RK_KMAT_BF16X3", "RK_KMAT_MFMA"):
+    for key in ("RK_KMAT_BF16X3", "RK_KMAT_MFMA", "RK_KMAT_SYM"):
         os.environ.pop(key, None)
     os.environ.update(MODES[mode])
 
