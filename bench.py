@@ -247,6 +247,25 @@ def main():
                     "avg_launch_ms": ms, "achieved_GBps": nbytes / (ms * 1e-3) / 1e9,
                     "frac_of_8000": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         del Ksh, vv
+    # ---- the storage-free alternative: the same product recomputed on the bf16 matrix cores ---------
+    matrix_free = None
+    if rank == 0 and world == 1 and args.dtype == "f32":
+        gcen = be.gram_center(Xd, Xd, 1.0)
+        vv = torch.randn(n, 1, dtype=dt, device=dev)
+        be.kernel_matmat("rbf", Xd, Xd, 1.0, vv, gram_center=gcen)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            be.kernel_matmat("rbf", Xd, Xd, 1.0, vv, gram_center=gcen)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        matrix_free = {"kernel": "rk_kernel_matmat (kmat_matmat_bf16x3_kernel, symmetric evaluation): K(X, X) v "
+                                 "recomputed from X, three-way bf16 split on the bf16 matrix cores, float32 accuracy",
+                       "avg_launch_ms": ms, "Gpair_per_s": n * n / ms / 1e6,
+                       "norm_bound_ok": gcen is not None}
+        del vv
     if world > 1:
         td.barrier()
 
@@ -310,6 +329,7 @@ def main():
             "matvec_GBps_aggregate": achieved * world,
             "matvec_dense_equivalent_GBps_aggregate": (n * n * float(es) / (mv["avg_ms"] * 1e-3) / 1e9) if mv["launches"] else None,
             "rowmajor_shard_product": rowmajor,
+            "matrix_free_product": matrix_free,
             "setup_materialize_s": round(t_mat, 3),
             "setup_nystrom_s": round(t_pre, 3),
             "rel_res_after_timed_steps": rel_now,
