@@ -21,4 +21,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$
 # matrix-free kernel product: the three formulations side by side, then the matrix-core busy counter
 timeout -k 10 300 python3 tools/bench_kmatmat.py > $OUT/${TAG}_bench_kmatmat.log 2>&1 && echo "kmatmat ok" && grep -c Gpair $OUT/${TAG}_bench_kmatmat.log
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_kmatmat -o ${TAG} -- python3 tools/bench_kmatmat.py --modes bf16x3 --reps 2 --cases 200000x200000x64x1,200000x200000x32x1,5000x500000x50x10g > $OUT/${TAG}_pmc_kmatmat.log 2>&1 && echo "pmc kmatmat ok"
+# many right-hand sides: packed symmetric and row-major streaming kernels
+timeout -k 10 300 python3 tools/bench_symm.py > $OUT/${TAG}_bench_symm.log 2>&1 && echo "symm ok"
+timeout -k 10 300 python3 tools/bench_skinny.py > $OUT/${TAG}_bench_skinny.log 2>&1 && echo "skinny ok"
+# storage-free PCG (matrix-free operator, symmetric evaluation)
+RK_KERNEL_MODE=matrix_free timeout -k 10 300 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-solve > $OUT/${TAG}_bench_matrix_free.log 2>&1 && echo "matrix-free pcg ok"
 ls -R $OUT | grep -c csv

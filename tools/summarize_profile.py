@@ -149,6 +149,18 @@ with open(f"{dst}/{tag}_summary.md", "w") as f:
                     gui = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"])
                     f.write(f"| `{kn}` | {grid} | {busy:.4g} | {100 * busy / (gui / 8.0 * 1024.0):.1f} % |\n")
             f.write("\n")
+    for name, title in (("symm", "Packed symmetric product, 1 .. 16 right-hand sides (tools/bench_symm.py)"),
+                        ("skinny", "Row-major shard product 25 000 x 200 000, 1 .. 16 right-hand sides (tools/bench_skinny.py)"),
+                        ("matrix_free", "Storage-free PCG: RK_KERNEL_MODE=matrix_free bench.py --steps 20")):
+        blog = f"{src}/{tag}_bench_{name}.log"
+        if not os.path.exists(blog):
+            continue
+        shutil.copy(blog, f"{dst}/{tag}_bench_{name}.log")
+        f.write(f"## {title}\n\n```\n")
+        for l in open(blog):
+            if l.startswith("{"):
+                f.write(l[:420].rstrip() + "\n")
+        f.write("```\n\n")
     f.write("## HBM traffic of the shard product (separate --pmc passes)\n\n")
     f.write(f"FETCH_SIZE = {fetch:.0f} KB, WRITE_SIZE = {write:.0f} KB per launch -> "
             f"(2 x FETCH + WRITE) x 1024 = {traffic / 1e9:.2f} GB vs algorithmic {algo / 1e9:.2f} GB "
