@@ -145,7 +145,8 @@ sympack_materialize_kernel(int kind, const T* __restrict__ X, int64_t ldx, int64
 //  * writing an item's tables at the START of the next item (second set of LDS buffers, the stores in
 //    flight together with that item's first loads, one barrier per item instead of two) changes
 //    nothing either: 12.45 vs 12.47 ms (round 2, tools/ab.py) - the cost of the stores is not a wait
-//    for their completion at the item boundary.
+//    for their completion at the item boundary.  Float atomics into an n-vector instead of the tables
+//    (no HBM writes at all; timing probe): 12.53 vs 12.45 ms - not the write traffic either.
 template <typename TS, typename T, int K>
 __global__ void __launch_bounds__(SYMM_THREADS)
 symm_strip_kernel(const TS* __restrict__ Kp, SymLayout L, const T* __restrict__ V, int64_t ldv,
