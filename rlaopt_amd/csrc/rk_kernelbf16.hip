@@ -108,9 +108,18 @@ gram_split_kernel(const float* __restrict__ X, int64_t ldx, const int64_t* __res
     *reinterpret_cast<bx_u4*>(dst + 2 * BX_SPLIT) = pack(ls);
 }
 
-constexpr size_t BX_SMEM_BYTES = 2 * BX_IMG + 2 * BX_VROWS * BX_LDV * sizeof(float) + 2 * BX_VROWS * sizeof(float);
+// k <= 4 (full evaluation): a 4-column V tile (50.5 KiB of LDS) and 138 registers admit 3 workgroups per
+// CU: +2 % at d = 64, +4.5 % at d = 32 (tools/ab.py --kernel kmatmat), bitwise identical results
+#ifndef RK_BX_WG3
+#define RK_BX_WG3 1
+#endif
+constexpr int bx_ldv(int kv) { return (RK_BX_WG3 && kv > 0) ? 4 : BX_LDV; }
+constexpr size_t bx_smem_bytes(int kv) {
+    return 2 * BX_IMG + 2 * BX_VROWS * bx_ldv(kv) * sizeof(float) + 2 * BX_VROWS * sizeof(float);
+}
+constexpr size_t BX_SMEM_BYTES = bx_smem_bytes(0);
 constexpr size_t bx_sym_smem_bytes(int kv) {  // + column sums [2][4 waves][64][kv] + 64 dummy slots
-    return BX_SMEM_BYTES + (size_t)(2 * 4 * 64 * kv + 64) * sizeof(float);
+    return bx_smem_bytes(kv) + (size_t)(2 * 4 * 64 * kv + 64) * sizeof(float);
 }
 
 // KV = 0: second product on the float32 matrix cores (k <= 16); KV = 1 / 2 / 4: on the VALU (k <= KV)
@@ -134,7 +143,7 @@ struct BxSym {
 };
 
 template <bool RBF, int KV, int NKS, bool SYM>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, ((RK_BX_WG3 && KV > 0 && !SYM) ? 3 : 2))
 kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, const unsigned char* __restrict__ img2,
                           int64_t n1, int64_t n2, float w, float scale, const float* __restrict__ nx,
                           const float* __restrict__ ny, const float* __restrict__ V, int k, int64_t ldv,
@@ -144,8 +153,9 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
     constexpr int TJ = G::TJ;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* XB = smem;                                                  // [2][BX_IMG]
-    float* VS = reinterpret_cast<float*>(smem + 2 * BX_IMG);                   // [2][BX_VROWS][BX_LDV]
-    float* NY = VS + 2 * BX_VROWS * BX_LDV;                                    // [2][BX_VROWS]
+    constexpr int LDV = bx_ldv(KV);
+    float* VS = reinterpret_cast<float*>(smem + 2 * BX_IMG);                   // [2][BX_VROWS][LDV]
+    float* NY = VS + 2 * BX_VROWS * LDV;                                       // [2][BX_VROWS]
     float* CS = NY + 2 * BX_VROWS;                                             // SYM: [2][4][64][KV] + dummy slots
     const float rbf_c = -0.5f * w * w * 1.4426950408889634f;  // exp(-s w^2 / 2) = exp2(rbf_c s)
     const float m2c = -2.f * rbf_c;
@@ -216,8 +226,13 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
         bx_u4* dst = reinterpret_cast<bx_u4*>(XB + buf * BX_IMG);
 #pragma unroll
         for (int q = 0; q < 6; ++q) dst[tid + 256 * q] = pre[q];
-        float* vs = VS + buf * BX_VROWS * BX_LDV + (tid >> 2) * BX_LDV + (tid & 3) * 4;
-        if (tid < 4 * TJ) *reinterpret_cast<float4*>(vs) = make_float4(vr[0], vr[1], vr[2], vr[3]);
+        if constexpr (LDV == 4) {  // only columns 0 .. 3 are kept (k <= 4)
+            if ((tid & 3) == 0 && tid < 4 * TJ)
+                *reinterpret_cast<float4*>(VS + buf * BX_VROWS * LDV + (tid >> 2) * LDV) = make_float4(vr[0], vr[1], vr[2], vr[3]);
+        } else {
+            float* vs = VS + buf * BX_VROWS * LDV + (tid >> 2) * LDV + (tid & 3) * 4;
+            if (tid < 4 * TJ) *reinterpret_cast<float4*>(vs) = make_float4(vr[0], vr[1], vr[2], vr[3]);
+        }
         if (tid < TJ) NY[buf * BX_VROWS + tid] = nyr * (RBF ? rbf_c : 1.f);
     };
 
@@ -256,7 +271,7 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
         const bool sym_tile = SYM && t >= t_sym;
         float* csw = CS + (buf * 4 + wave) * 64 * KVS;
         const unsigned char* xb = XB + buf * BX_IMG;
-        const float* vsb = VS + buf * BX_VROWS * BX_LDV;
+        const float* vsb = VS + buf * BX_VROWS * LDV;
         const float* nyb = NY + buf * BX_VROWS;
 #pragma unroll
         for (int jb = 0; jb < G::JB; ++jb) {
@@ -302,7 +317,7 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
                         p[ib] = kernel_value<float>(kind, s, w);
                     }
                 }
-                const float* vj = vsb + (jb * 16 + 4 * lq + v) * BX_LDV;
+                const float* vj = vsb + (jb * 16 + 4 * lq + v) * LDV;
                 if constexpr (KV == 0) {
                     const float av = vj[lr];  // A operand: V[j = 4 (lane / 16) + v][rhs = lane % 16]
 #pragma unroll
@@ -532,7 +547,7 @@ int launch_kmatmat_bf16x3(int kind, const float* X1, int64_t n1, int64_t ldx1, c
     const int nks = d <= 32 ? 1 : (d <= 64 ? 2 : 4);
     dim3 grid((unsigned)ceil_div(n1, BX_TI), (unsigned)S);
 #define RK_BX_N(RBFV, KVV, NKSV)                                                                           \
-    hipLaunchKernelGGL((kmat_matmat_bf16x3_kernel<RBFV, KVV, NKSV, false>), grid, dim3(256), BX_SMEM_BYTES, \
+    hipLaunchKernelGGL((kmat_matmat_bf16x3_kernel<RBFV, KVV, NKSV, false>), grid, dim3(256), bx_smem_bytes(KVV), \
                        st, kind, img1, img2, n1, n2, w, scale, nxp, nyp, V, k, ldv, tiles_per_seg, part, Y, ldy, \
                        accumulate, BxSym{})
 #define RK_BX(RBFV, KVV)                                                                                   \
