@@ -224,7 +224,18 @@ def test_fullsize_packed_symmetric_product(be, full_problem):
     a = (ud.double() * Kv.double()).sum(0)
     b = (vd.double() * Ku.double()).sum(0)
     assert float(((a - b).abs() / a.abs().clamp_min(1.0)).max()) < 1e-4
-    del Kp, Ku, free
+    # many right-hand sides in ONE pass (matrix-core strip kernel): linearity against the k <= 4 products,
+    # sampled rows of the C oracle, bitwise reproducibility
+    g = torch.Generator().manual_seed(9)
+    C = torch.randn(vd.shape[1] + 1, 10, generator=g).to(DEV)           # 10 columns mixing [v, u]
+    Wd = torch.cat([vd, ud[:, :1]], dim=1) @ C
+    Yw = be.symm_matmat(Kp, n, Wd)
+    assert torch.equal(Yw, be.symm_matmat(Kp, n, Wd))
+    lin = torch.cat([Kv, Ku[:, :1]], dim=1).double() @ C.double()
+    assert float((Yw.double() - lin).norm() / lin.norm()) < 2e-5
+    want_w = cbind.kernel_matmat("rbf", X[rows], X, 1.0, Wd.cpu())
+    assert float((Yw[rows.to(DEV)].cpu() - want_w).norm() / want_w.norm()) < 2e-5
+    del Kp, Ku, free, Yw, Wd
     torch.cuda.empty_cache()
     # the 8-rank layout: rank r owns strips r, r + 8, ...; the partial products add up
     total = torch.zeros_like(y)
