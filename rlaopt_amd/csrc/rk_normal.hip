@@ -79,11 +79,13 @@ normal_pass_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
         for (int r = 0; r < R; ++r) {
             int64_t i = i0 + r;
             if (i > m - 1) i = m - 1;  // clamp; masked below
+            // (unconditional: a lane whose columns lie past n re-reads the first 16 bytes of its column
+            // chunk - every chunk starts inside the row - and is masked when the data is used; a
+            // conditional load makes the compiler drain the whole prefetch queue at the branch join,
+            // once per group of rows)
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                if (col_ok[s]) a[r][s] = load_stream_at<V16>(A + i * lda + (int64_t)s * 64 * VW, lane_off);
-                else a[r][s] = V16{};
-            }
+            for (int s = 0; s < NS; ++s)
+                a[r][s] = load_stream_at<V16>(A + i * lda + (int64_t)s * 64 * VW, col_ok[s] ? lane_off : 0u);
         }
     };
     auto consume = [&](const V16 a[R][NS], T uo, int64_t i0) {
@@ -96,7 +98,7 @@ normal_pass_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
             for (int s = 0; s < NS; ++s) {
                 const T* p = reinterpret_cast<const T*>(&a[r][s]);
 #pragma unroll
-                for (int e = 0; e < VW; ++e) ae[s][e] = p[e];
+                for (int e = 0; e < VW; ++e) ae[s][e] = col_ok[s] ? p[e] : T(0);
             }
             T unew[K];
 #pragma unroll
