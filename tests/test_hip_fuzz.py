@@ -1,0 +1,101 @@
+"""Seeded random shapes through the GPU kernels added in round 2 - the bf16 matrix-core product in
+all its instantiations (1 / 2 / 4 k-steps, VALU or matrix-core second product, gathered operands,
+symmetric evaluation), the matrix-core streaming kernels for many right-hand sides (packed symmetric
+and row-major) - each against the float64 oracle.  Shapes are drawn around the tile edges (64 / 128
+points, 32 / 64 / 128 features, 256 columns) where padding and masking decide."""
+
+import random
+
+import pytest
+import torch
+
+from oracle import kernels as ok
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def be():
+    from rlaopt_amd.ops import get_backend
+
+    return get_backend()
+
+
+def _near(rng, centers, spread):
+    c = rng.choice(centers)
+    return max(1, c + rng.randint(-spread, spread))
+
+
+def rel_err(a, b):
+    return float((a.double().cpu() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_matrix_free_product_random_shapes(be, monkeypatch, seed):
+    rng = random.Random(1000 + seed)
+    monkeypatch.setenv("RK_KMAT_SYM_MINN", "1")
+    n1 = _near(rng, [1, 64, 128, 129, 300, 1000], 3)
+    n2 = _near(rng, [128, 192, 256, 700, 2049], 5)
+    if n2 < 128:
+        n2 = 128
+    d = _near(rng, [1, 8, 32, 33, 64, 65, 100, 128], 1)
+    d = min(d, 128)
+    k = rng.choice([1, 2, 3, 4, 5, 10, 16, 17])
+    kind = rng.choice(["rbf", "matern32", "matern52"])
+    ard = rng.random() < 0.3
+    gen = torch.Generator().manual_seed(seed)
+    offset = 3.0 if rng.random() < 0.3 else 0.0  # un-centred data: the panels are centred in the kernel
+    X2 = offset + torch.randn(n2, d, generator=gen) / d**0.5
+    same = rng.random() < 0.4
+    X1 = X2 if same else offset + torch.randn(n1, d, generator=gen) / d**0.5
+    if same:
+        n1 = n2
+    ls = (0.7 + 0.6 * torch.rand(d, generator=gen)) if ard else 0.9
+    V = torch.randn(n2, k, generator=gen)
+    idx1 = idx2 = None
+    if rng.random() < 0.4:
+        idx1 = torch.randperm(X1.shape[0], generator=gen)[: max(1, X1.shape[0] // 2)]
+        if same and rng.random() < 0.5 and idx1.numel() >= 128:  # the block oracle: one shared gather
+            idx2 = idx1
+            V = V[: idx1.numel()]
+    X1d, X2d = X1.to(DEV), (X1.to(DEV) if same else X2.to(DEV))
+    if same:
+        X2d = X1d
+    lsd = ls.to(DEV) if ard else ls
+    i1 = None if idx1 is None else idx1.to(DEV)
+    i2 = None if idx2 is None else (i1 if idx2 is idx1 else idx2.to(DEV))
+    got = be.kernel_matmat(kind, X1d, X2d, lsd, V.to(DEV), scale=1.3, idx1=i1, idx2=i2)
+    want = ok.kernel_matmat(kind, X1.double(), X2.double(), ls.double() if ard else ls, V.double(), 1.3,
+                            idx1=idx1, idx2=idx2)
+    assert got.shape == want.shape
+    assert rel_err(got, want) < 3e-5, (n1, n2, d, k, kind, ard, same, idx1 is not None, idx2 is not None)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_streaming_products_many_columns_random_shapes(be, seed):
+    rng = random.Random(2000 + seed)
+    gen = torch.Generator().manual_seed(seed)
+    # packed symmetric, 5 .. 16 columns through the matrix-core strip kernel
+    n = _near(rng, [255, 256, 257, 1024, 1025, 2300], 2)
+    k = rng.randint(5, 16)
+    X = torch.randn(n, 6, generator=gen) / 6**0.5
+    V = torch.randn(n, k, generator=gen)
+    K = ok.kernel_matrix("rbf", X.double(), X.double(), 1.0, 1.0)
+    stride = rng.choice([1, 2, 3])
+    total = torch.zeros(n, k, dtype=torch.float64)
+    for first in range(stride):
+        Kp = be.sympack_materialize("rbf", X.to(DEV), 1.0, first=first, stride=stride)
+        total += be.symm_matmat(Kp, n, V.to(DEV), first=first, stride=stride).double().cpu()
+    assert rel_err(total, K @ V.double()) < 1e-4 / 2, (n, k, stride)
+    # row-major, 10 .. 16 columns through the matrix-core kernel (n % 4 == 0, padded leading dimension)
+    m = _near(rng, [1, 31, 32, 33, 500], 1)
+    nn = 4 * _near(rng, [64, 65, 200, 1000], 2)
+    kk = rng.randint(10, 16)
+    pad = rng.choice([0, 4, 12])
+    Afull = torch.randn(m, nn + pad, generator=gen)
+    A = Afull[:, :nn]
+    W = torch.randn(nn, kk, generator=gen)
+    C = torch.randn(m, kk, generator=gen)
+    got = be.matmat(Afull.to(DEV)[:, :nn], W.to(DEV), alpha=0.5, beta=-1.0, C=C.to(DEV))
+    assert rel_err(got, 0.5 * A.double() @ W.double() - C.double()) < 1e-4 / 2, (m, nn, kk, pad)
