@@ -109,7 +109,8 @@ gram_split_kernel(const float* __restrict__ X, int64_t ldx, const int64_t* __res
 }
 
 // k <= 4 (full evaluation): a 4-column V tile (50.5 KiB of LDS) and 138 registers admit 3 workgroups per
-// CU: +2 % at d = 64, +4.5 % at d = 32 (tools/ab.py --kernel kmatmat), bitwise identical results
+// CU: +2 % at d = 64, +4.5 % at d = 32 (tools/ab.py --kernel kmatmat), bitwise identical results.  (The
+// symmetric evaluation at 3 per CU - k = 1 fits the LDS - spills 10 registers: 19.5 instead of 18.1 ms.)
 #ifndef RK_BX_WG3
 #define RK_BX_WG3 1
 #endif
