@@ -101,6 +101,8 @@ def _gram_center(kind: str, A1: torch.Tensor, A2: torch.Tensor, lengthscale, dev
     return be.gram_center(A1d, A2d, ell)
 
 
+_FREE_WIDE_COLS = 96     # matrix-free operators: beyond this many columns panels + GEMM beat the fused product
+_FREE_PANEL_BYTES = 8 << 30  # their temporary panel (a matrix-free operator is chosen to keep allocations small)
 _PANEL_BYTES = 16 << 30  # temporary row-major panel for wide products in sympack mode (>= 512 GEMM tiles)
 _BLK_MATERIALIZE_BYTES = 1 << 30  # block oracles up to this size are materialised (SAP blocks)
 _SYM_MAX_COLS = 16      # beyond this many columns a product goes through panels + MFMA
@@ -218,13 +220,39 @@ class _KernelBlock:
         if self.materialised:
             return be.matmat(self.K, x, alpha=alpha, beta=beta, C=C, diag_shift=diag_shift, row0=row0,
                              tag="kernel_shard_product")
-        y = be.kernel_matmat(self.kind, self.A1, self.A2, self.config.lengthscale, x, scale=self.scale,
-                             gram_center=self.gram_center)
+        cols = 1 if x.ndim == 1 else x.shape[1]
+        if cols > _FREE_WIDE_COLS:
+            # many columns (the Nystrom sketch): the fused product recomputes the kernel entries once per
+            # 16 columns (36 ms each at n = 200 000); beyond ~100 columns temporary row-major panels and
+            # the matrix-core GEMM are cheaper (0.19 s of entries + 0.7 ms per column)
+            y = self._matmat_wide(x)
+        else:
+            y = be.kernel_matmat(self.kind, self.A1, self.A2, self.config.lengthscale, x, scale=self.scale,
+                                 gram_center=self.gram_center)
         if diag_shift != 0.0:
             y = y + diag_shift * x[row0 : row0 + y.shape[0]]
         if alpha != 1.0 or beta != 0.0:
             y = alpha * y + (beta * C if beta != 0.0 else 0.0)
         return y
+
+    def _matmat_wide(self, x):
+        be = get_backend()
+        m, n = self.A1.shape[0], self.A2.shape[0]
+        es = x.element_size()
+        budget = _FREE_PANEL_BYTES
+        if x.is_cuda:
+            budget = min(budget, int(0.5 * torch.cuda.mem_get_info(x.device)[0]))
+        rpp = max(256, min(m, budget // (n * es)))
+        if rpp >= 8192:
+            rpp -= rpp % 8192  # whole rounds of 128 x 128 GEMM tiles (see _SymPackBlock.rows_matmat_wide)
+        panel = torch.empty((min(rpp, m), n), dtype=x.dtype, device=x.device)
+        out = torch.empty((m, x.shape[1]), dtype=x.dtype, device=x.device)
+        for a in range(0, m, rpp):
+            b = min(m, a + rpp)
+            K = be.kernel_materialize(self.kind, self.A1[a:b], self.A2, self.config.lengthscale,
+                                      scale=self.scale, out=panel[: b - a])
+            out[a:b] = be.matmat(K, x)
+        return out
 
     def rmatmat(self, x):
         be = get_backend()

@@ -605,3 +605,25 @@ def test_kernel_matmat_symmetric_evaluation(be, monkeypatch, kind, n, d, k):
                                   idx1=blk.cpu(), idx2=blk.cpu())
         got_b = be.kernel_matmat(kind, Xd, Xd, 0.9, Vb, scale=1.25, idx1=blk, idx2=blk, gram_center=gc)
         assert rel_err(got_b.cpu(), want_b) < LIM[dt]
+
+
+def test_matrix_free_operator_wide_product_uses_panels(be, monkeypatch, prec):
+    """RK_KERNEL_MODE=matrix_free: a product with many columns (the Nystrom sketch) goes through
+    temporary row-major panels + the matrix-core GEMM, a narrow one through the fused kernel; both
+    equal the dense product.  A tiny panel budget forces several panels."""
+    import rlaopt_amd.kernels.base as kb
+    from rlaopt_amd.kernels import KernelConfig, RBFLinOp
+
+    dt = DTYPES[prec]
+    monkeypatch.setenv("RK_KERNEL_MODE", "matrix_free")
+    monkeypatch.setattr(kb, "_FREE_PANEL_BYTES", 300 * 700 * 8)  # ~300 rows per panel
+    gen = torch.Generator().manual_seed(4)
+    n, d = 700, 9
+    X = (torch.randn(n, d, dtype=dt, generator=gen) / d**0.5)
+    A = RBFLinOp(X.to(dev()), X.to(dev()), KernelConfig(lengthscale=1.1, const_scaling=0.7))
+    assert A.storage_mode == "matrix_free"
+    K = ok.kernel_matrix("rbf", X.double(), X.double(), 1.1, 0.7)
+    for cols in (3, 130):
+        M = torch.randn(n, cols, dtype=dt, generator=gen)
+        got = A @ M.to(dev())
+        assert rel_err(got.cpu(), K @ M.double()) < LIM[dt] * 5, cols
