@@ -119,10 +119,10 @@ int rk_kernel_gram_bound(int dtype, const void* X, int64_t n, int64_t ldx, int64
  * ranks).  Half the bytes of the row-major block; rk_symm_matmat reads every stored entry once
  * and uses it for y[i] += K[i][j] v[j] AND y[j] += K[i][j] v[i].  The result of rk_symm_matmat
  * is this rank's PARTIAL sum over its strips (complete when strip_stride == 1); partials of
- * different ranks add up to K V (all-reduce).  1 <= k <= 4 per call (register kernel); float32
- * with float32 storage also 5 <= k <= 16 (matrix-core strip kernel: both uses of a stored entry
- * as v_mfma_f32_16x16x4_f32 products out of LDS-staged tiles, one pass for up to 16 right-hand
- * sides).  No reference
+ * different ranks add up to K V (all-reduce).  1 <= k <= 4 per call (register kernel); with
+ * store_dtype == dtype also 5 <= k <= 16 (matrix-core strip kernel: both uses of a stored entry
+ * as v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64 products out of LDS-staged tiles, one pass
+ * for up to 16 right-hand sides).  No reference
  * counterpart: the reference never exploits A1 is A2 (rlaopt/kernels/base.py:23-128). */
 /* `store_dtype` is the element type of the packed matrix: equal to `dtype`, or RK_F32 under
  * RK_F64 arithmetic ("fp32 storage, fp64 iteration": entries are computed in float64 and

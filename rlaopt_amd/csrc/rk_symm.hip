@@ -311,43 +311,70 @@ symm_strip_kernel(const TS* __restrict__ Kp, SymLayout L, const T* __restrict__ 
 // rows x one chunk, one row x 16 chunks) are bank-conflict free.  V is first copied into a zero-
 // padded [round_up(n, 256)][16] array so that every operand load is an aligned, unconditional one.
 constexpr int SMK = 16;                        // right-hand sides carried (k is padded up to it)
-template <int TR>
-constexpr size_t sm_smem_bytes() {  // staged tiles + V rows of the tile + row parts of the column slices
-    return (size_t)(2 * TR * 256 + 2 * TR * SMK + 2 * (4 / (TR / 16)) * TR * SMK) * sizeof(float);
+template <typename T, int TR>
+constexpr size_t sm_smem_bytes() {  // staged tiles (TR KiB each) + V rows of the tile + row parts of the column slices
+    return (size_t)(2 * TR * 1024) + (size_t)(2 * TR * SMK + 2 * (4 / (TR / 16)) * TR * SMK) * sizeof(T);
 }
 
-typedef float sm_acc __attribute__((ext_vector_type(4)));
+template <typename T>
+struct SmAcc;
+template <>
+struct SmAcc<float> {
+    typedef float type __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ type mfma(float a, float b, type c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    // accumulator element v of lane (lq = lane / 16) sits in row m of the 16 x 16 result
+    static __device__ __forceinline__ int row(int lq, int v) { return 4 * lq + v; }
+};
+template <>
+struct SmAcc<double> {
+    typedef double type __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ type mfma(double a, double b, type c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lq, int v) { return lq + 4 * v; }  // (the f64 layout differs)
+};
 
+template <typename T>
 __global__ void __launch_bounds__(256)
-symm_pad_v_kernel(const float* __restrict__ V, int64_t n, int64_t npad, int k, int64_t ldv, float* __restrict__ Vp) {
+symm_pad_v_kernel(const T* __restrict__ V, int64_t n, int64_t npad, int k, int64_t ldv, T* __restrict__ Vp) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= npad * SMK) return;
     const int64_t i = e / SMK;
     const int c = (int)(e - i * SMK);
-    Vp[e] = (i < n && c < k) ? V[i * ldv + c] : 0.f;
+    Vp[e] = (i < n && c < k) ? V[i * ldv + c] : T(0);
 }
 
-__device__ __forceinline__ int sm_at(int row, int chunk) {  // float index of 16-byte chunk `chunk` of a staged row
-    return row * 256 + ((chunk ^ (row & 15)) << 2);
+// element index of 16-byte chunk `chunk` (0 .. 63) of staged row `row` (rows are 1 KiB)
+template <typename T>
+__device__ __forceinline__ int sm_at(int row, int chunk) {
+    return (row * 64 + (chunk ^ (row & 15))) * Vec16<T>::N;
 }
 
-// TR = rows per tile: 32 (76 KiB of LDS, 2 workgroups per CU; row part split 2 row blocks x 2 column
-// halves over the waves) or 16 (38 KiB, 4 workgroups per CU; 1 row block x 4 column quarters)
-template <int TR>
-__global__ void __launch_bounds__(SYMM_THREADS, (TR == 32 ? 2 : 4))
-symm_strip_mfma_kernel(const float* __restrict__ Kp, SymLayout L, const float* __restrict__ Vp,
-                       float* __restrict__ Prow, float* __restrict__ Pcol, int64_t max_items,
+// TR = rows per tile: 32 (2 row blocks x 2 column halves over the waves) or 16 (1 row block x 4 column
+// quarters).  float: TR = 32 at 76 KiB of LDS, 2 workgroups per CU (TR = 16: 4 per CU, 1 % slower);
+// double: TR = 16 at 52 KiB (the float64 row parts do not fit beside 32-row tiles twice per CU).
+template <typename T, int TR>
+__global__ void __launch_bounds__(SYMM_THREADS, (TR == 32 ? 2 : (sizeof(T) == 4 ? 4 : 3)))
+symm_strip_mfma_kernel(const T* __restrict__ Kp, SymLayout L, const T* __restrict__ Vp,
+                       T* __restrict__ Prow, T* __restrict__ Pcol, int64_t max_items,
                        int64_t total_items) {
-    constexpr int W = 256;
+    using V16 = typename Vec16<T>::type;
+    using Acc = typename SmAcc<T>::type;
+    constexpr int VW = Vec16<T>::N;       // elements per 16-byte chunk: 4 / 2
+    constexpr int W = 64 * VW;            // strip width: 256 / 128 columns
     constexpr int NRB = TR / 16;          // 16-row blocks per tile
     constexpr int NCS = 4 / NRB;          // column slices of the row part (one per wave and row block)
-    constexpr int CSW = W / NCS;          // columns per slice: 128 or 64
-    constexpr int NS = CSW / 16;          // 16-column steps per slice: 8 or 4
+    constexpr int CSW = W / NCS;          // columns per slice
+    constexpr int NS = CSW / (4 * VW);    // ds_read_b128 steps per slice (4 lane groups x VW columns each)
+    constexpr int CW = W / 4;             // columns per wave in the column part
     constexpr int RPW = TR / 4;           // staged rows per wave
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* TB = sm;                              // [2][TR][256]        staged tiles (swizzled)
-    float* VI = TB + 2 * TR * W;                 // [2][TR][SMK]        V rows of the tile
-    float* RP = VI + 2 * TR * SMK;               // [2][NCS][TR][SMK]   row parts of the column slices
+    constexpr int VPT = TR * SMK / SYMM_THREADS;  // V-tile elements per thread: 2 or 1
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
+    T* TB = reinterpret_cast<T*>(sm_raw);        // [2][TR][W]          staged tiles (swizzled)
+    T* VI = TB + 2 * TR * W;                     // [2][TR][SMK]        V rows of the tile
+    T* RP = VI + 2 * TR * SMK;                   // [2][NCS][TR][SMK]   row parts of the column slices
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -366,57 +393,64 @@ symm_strip_mfma_kernel(const float* __restrict__ Kp, SymLayout L, const float* _
         const int64_t item_lo = uniform64(chunk * ITEM_ROWS);
         const int64_t item_hi = item_lo + ITEM_ROWS < nrows ? item_lo + ITEM_ROWS : nrows;
         const int64_t diag_lo = uniform64(L.strip(t) * W);
-        const float* base = Kp + uniform64(L.row_offset(t) * W);
+        const T* base = Kp + uniform64(L.row_offset(t) * W);
         const int ntile = (int)((item_hi - item_lo + TR - 1) / TR);
 
-        // B operands of the row part: V[diag_lo + CSW cs + 16 s + 4 lq + q][rhs = lr]
-        float vB[NS][4];
+        // B operands of the row part: V[diag_lo + CSW cs + 4 VW s + VW lq + q][rhs = lr]
+        T vB[NS][VW];
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                vB[s][q] = Vp[(diag_lo + CSW * cs + 16 * s + 4 * lq + q) * SMK + lr];
-        sm_acc ccol[4];
+            for (int q = 0; q < VW; ++q)
+                vB[s][q] = Vp[(diag_lo + CSW * cs + 4 * VW * s + VW * lq + q) * SMK + lr];
+        Acc ccol[VW];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < VW; ++q)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) ccol[q][v] = 0.f;
+            for (int v = 0; v < 4; ++v) ccol[q][v] = T(0);
 
         // staging: per load instruction a wave fetches one whole stored row (1 KiB).  TWO tiles are in
         // flight per workgroup (register sets A / B, the tile loop is unrolled by two): with one, the
         // loads of a tile land in the first half of the previous tile's arithmetic and nothing is
-        // outstanding for the rest of it - 32 KiB per CU on average, below what the HBM pipeline
-        // needs (measured: 4.2 TB/s)
-        float4 preA[RPW], preB[RPW], vpreA, vpreB;
-        auto load_tile = [&](int tl, float4 (&pre)[RPW], float4& vpre) {
+        // outstanding for the rest of it
+        V16 preA[RPW], preB[RPW];
+        T vpreA[VPT], vpreB[VPT];
+        auto load_tile = [&](int tl, V16 (&pre)[RPW], T (&vpre)[VPT]) {
             const int64_t r0 = item_lo + (int64_t)(tl < ntile ? tl : ntile - 1) * TR;
 #pragma unroll
             for (int u = 0; u < RPW; ++u) {
                 const int64_t i = r0 + wave + 4 * u;
-                const int64_t ic = i < nrows ? i : nrows - 1;
-                const float4 x = load_stream_at<float4>(base + ic * W, (unsigned)lane * 16u);
-                const float m = i < item_hi ? 1.f : 0.f;  // rows past the item: exact zeros
-                pre[u] = make_float4(x.x * m, x.y * m, x.z * m, x.w * m);
+                pre[u] = load_stream_at<V16>(base + (i < nrows ? i : nrows - 1) * W, (unsigned)lane * 16u);
             }
-            const int64_t iv = r0 + ((tid >> 2) & (TR - 1));
-            vpre = *reinterpret_cast<const float4*>(Vp + (iv < nrows ? iv : nrows - 1) * SMK + (tid & 3) * 4);
-        };
-        auto store_tile = [&](int buf, const float4 (&pre)[RPW], const float4& vpre) {
-            float* tb = TB + buf * TR * W;
 #pragma unroll
-            for (int u = 0; u < RPW; ++u)
-                *reinterpret_cast<float4*>(tb + sm_at(wave + 4 * u, lane)) = pre[u];
-            // (every thread stores: threads past 4 TR hold - and rewrite - the values of row (tid / 4) % TR;
-            // a divergent store makes the compiler drain ALL outstanding loads in front of it)
-            *reinterpret_cast<float4*>(VI + buf * TR * SMK + ((tid >> 2) & (TR - 1)) * SMK + (tid & 3) * 4) = vpre;
+            for (int e = 0; e < VPT; ++e) {
+                const int at = tid * VPT + e;  // element (row at / 16, rhs at % 16) of the tile's V rows
+                const int64_t iv = r0 + at / SMK;
+                vpre[e] = Vp[(iv < nrows ? iv : nrows - 1) * SMK + at % SMK];
+            }
+        };
+        auto store_tile = [&](int buf, int tl, const V16 (&pre)[RPW], const T (&vpre)[VPT]) {
+            T* tb = TB + buf * TR * W;
+            const int64_t r0 = item_lo + (int64_t)(tl < ntile ? tl : ntile - 1) * TR;
+#pragma unroll
+            for (int u = 0; u < RPW; ++u) {
+                const T m = r0 + wave + 4 * u < item_hi ? T(1) : T(0);  // rows past the item: exact zeros
+                V16 x = pre[u];
+                T* xe = reinterpret_cast<T*>(&x);
+#pragma unroll
+                for (int e = 0; e < VW; ++e) xe[e] *= m;
+                *reinterpret_cast<V16*>(tb + sm_at<T>(wave + 4 * u, lane)) = x;
+            }
+#pragma unroll
+            for (int e = 0; e < VPT; ++e) VI[buf * TR * SMK + tid * VPT + e] = vpre[e];
         };
         auto flush_rows = [&](int buf, int tl) {  // add the column slices, store to the row table
-            const float* rp = RP + buf * NCS * TR * SMK;
-            float* pr = Prow + (L.row_offset(t) + item_lo + (int64_t)tl * TR) * SMK;
+            const T* rp = RP + buf * NCS * TR * SMK;
+            T* pr = Prow + (L.row_offset(t) + item_lo + (int64_t)tl * TR) * SMK;
             const int64_t live = (item_hi - item_lo - (int64_t)tl * TR) * SMK;
 #pragma unroll
             for (int e = tid; e < TR * SMK; e += SYMM_THREADS) {
-                float sum = rp[e];
+                T sum = rp[e];
 #pragma unroll
                 for (int c = 1; c < NCS; ++c) sum += rp[c * TR * SMK + e];
                 if (e < live) __builtin_nontemporal_store(sum, &pr[e]);
@@ -424,60 +458,61 @@ symm_strip_mfma_kernel(const float* __restrict__ Kp, SymLayout L, const float* _
         };
         auto compute = [&](int buf, int tl) {
             if (tl > 0) flush_rows(buf ^ 1, tl - 1);  // (RP[buf ^ 1] was completed before the last barrier)
-            const float* tb = TB + buf * TR * W;
-            // ---- row part ---------------------------------------------------------------------
-            sm_acc crow = {0.f, 0.f, 0.f, 0.f};
+            const T* tb = TB + buf * TR * W;
+            // ---- row part: lane (row lr, column group lq), VW columns per read ---------------------
+            Acc crow;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) crow[v] = T(0);
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                const float4 a = *reinterpret_cast<const float4*>(tb + sm_at(16 * rb + lr, (CSW / 4) * cs + 4 * s + lq));
-                crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, vB[s][0], crow, 0, 0, 0);
-                crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, vB[s][1], crow, 0, 0, 0);
-                crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, vB[s][2], crow, 0, 0, 0);
-                crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, vB[s][3], crow, 0, 0, 0);
-            }
-            float* rp = RP + (buf * NCS + cs) * TR * SMK;
+                const V16 a = *reinterpret_cast<const V16*>(tb + sm_at<T>(16 * rb + lr, (CSW / VW) * cs + 4 * s + lq));
+                const T* ae = reinterpret_cast<const T*>(&a);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) rp[(16 * rb + 4 * lq + v) * SMK + lr] = crow[v];
-            // ---- column part (rows above the diagonal block only; tile-uniform) ----------------
+                for (int q = 0; q < VW; ++q) crow = SmAcc<T>::mfma(ae[q], vB[s][q], crow);
+            }
+            T* rp = RP + (buf * NCS + cs) * TR * SMK;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) rp[(16 * rb + SmAcc<T>::row(lq, v)) * SMK + lr] = crow[v];
+            // ---- column part (rows above the diagonal block only; tile-uniform): lane (column group
+            // lr, row lq) ------------------------------------------------------------------------
             if (item_lo + (int64_t)tl * TR < diag_lo) {
-                const float* vi = VI + buf * TR * SMK;
+                const T* vi = VI + buf * TR * SMK;
 #pragma unroll
                 for (int s = 0; s < TR / 4; ++s) {
-                    const float4 a = *reinterpret_cast<const float4*>(tb + sm_at(4 * s + lq, 16 * wave + lr));
-                    const float b = vi[(4 * s + lq) * SMK + lr];
-                    ccol[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b, ccol[0], 0, 0, 0);
-                    ccol[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b, ccol[1], 0, 0, 0);
-                    ccol[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b, ccol[2], 0, 0, 0);
-                    ccol[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b, ccol[3], 0, 0, 0);
+                    const V16 a = *reinterpret_cast<const V16*>(tb + sm_at<T>(4 * s + lq, 16 * wave + lr));
+                    const T* ae = reinterpret_cast<const T*>(&a);
+                    const T bq = vi[(4 * s + lq) * SMK + lr];
+#pragma unroll
+                    for (int q = 0; q < VW; ++q) ccol[q] = SmAcc<T>::mfma(ae[q], bq, ccol[q]);
                 }
             }
         };
 
         load_tile(0, preA, vpreA);
-        store_tile(0, preA, vpreA);
+        store_tile(0, 0, preA, vpreA);
         load_tile(1, preA, vpreA);
         load_tile(2, preB, vpreB);
         __syncthreads();
         for (int tl = 0; tl < ntile; tl += 2) {
-            store_tile(1, preA, vpreA);        // tile tl + 1
+            store_tile(1, tl + 1, preA, vpreA);
             load_tile(tl + 3, preA, vpreA);
             compute(0, tl);
             __syncthreads();  // tile tl + 1 staged, RP[0] complete, everyone done with TB[0]
             if (tl + 1 < ntile) {
-                store_tile(0, preB, vpreB);    // tile tl + 2
+                store_tile(0, tl + 2, preB, vpreB);
                 load_tile(tl + 4, preB, vpreB);
                 compute(1, tl + 1);
                 __syncthreads();
             }
         }
         flush_rows((ntile - 1) & 1, ntile - 1);
-        // column sums of the item: ccol[q][v] = Ycol[column 64 w + 4 (4 lq + v) + q][rhs = lr]
-        float* pc = Pcol + ((t * max_items + chunk) * W) * SMK;
+        // column sums of the item: ccol[q][v] = Ycol[column CW w + VW m + q][rhs = lr], m = row(lq, v)
+        T* pc = Pcol + ((t * max_items + chunk) * W) * SMK;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < VW; ++q)
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                __builtin_nontemporal_store(ccol[q][v], &pc[(64 * wave + 4 * (4 * lq + v) + q) * SMK + lr]);
+                __builtin_nontemporal_store(ccol[q][v], &pc[(CW * wave + VW * SmAcc<T>::row(lq, v) + q) * SMK + lr]);
         __syncthreads();  // RP / TB are reused by the next item
     }
 }
@@ -641,17 +676,17 @@ static int symm_matmat_impl(const TS* Kp, int64_t n, int64_t first, int64_t stri
     return launch_status("rk_symm_matmat(finish)");
 }
 
-// ---- 5 <= k <= 16 right-hand sides (float32): the matrix-core strip kernel ---------------------------
-template <int TR>
-static int launch_symm_mfma(const float* Kp, const SymLayout& L, const float* Vp, float* Prow, float* Pcol,
+// ---- 5 <= k <= 16 right-hand sides: the matrix-core strip kernel -------------------------------------
+template <typename T, int TR>
+static int launch_symm_mfma(const T* Kp, const SymLayout& L, const T* Vp, T* Prow, T* Pcol,
                             int64_t max_items, int64_t total_items, hipStream_t st) {
-    constexpr size_t smem = sm_smem_bytes<TR>();
+    constexpr size_t smem = sm_smem_bytes<T, TR>();
     static std::atomic<unsigned long long> attr_devs{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (smem > 65536 && !(attr_devs.load(std::memory_order_acquire) & bit)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(symm_strip_mfma_kernel<TR>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(symm_strip_mfma_kernel<T, TR>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
             (void)hipGetLastError();
             set_error("rk_symm_matmat: cannot reserve %zu bytes of LDS", smem);
@@ -659,60 +694,78 @@ static int launch_symm_mfma(const float* Kp, const SymLayout& L, const float* Vp
         }
         attr_devs.fetch_or(bit, std::memory_order_release);
     }
-    const int64_t resident = symm_resident_workgroups(symm_strip_mfma_kernel<TR>, TR == 32 ? 2 : 4);
+    const int per_cu = TR == 32 ? 2 : (sizeof(T) == 4 ? 4 : 3);
+    const int64_t resident = symm_resident_workgroups(symm_strip_mfma_kernel<T, TR>, per_cu);
     dim3 grid((unsigned)(total_items < resident ? total_items : resident));
-    hipLaunchKernelGGL((symm_strip_mfma_kernel<TR>), grid, dim3(SYMM_THREADS), smem, st, Kp, L, Vp, Prow, Pcol,
+    hipLaunchKernelGGL((symm_strip_mfma_kernel<T, TR>), grid, dim3(SYMM_THREADS), smem, st, Kp, L, Vp, Prow, Pcol,
                        max_items, total_items);
     return RK_OK;
 }
 
+template <typename T>
 static size_t symm_wide_ws_bytes(int64_t n, int64_t first, int64_t stride) {
-    const SymLayout L = make_layout<float>(n, first, stride);
+    const SymLayout L = make_layout<T>(n, first, stride);
     const int64_t max_items = ceil_div(n, ITEM_ROWS);
     const size_t vp = (size_t)round_up(n, 256) * SMK;
     const size_t prow = (size_t)L.total_rows() * SMK;
     const size_t pcol = (size_t)L.strips_local() * max_items * L.W * SMK;
-    return (vp + prow + pcol) * sizeof(float);
+    return (vp + prow + pcol) * sizeof(T);
 }
 
-static int symm_matmat_wide_impl(const float* Kp, int64_t n, int64_t first, int64_t stride, const float* V,
-                                 int64_t k, int64_t ldv, double alpha, double shift, float* Y, int64_t ldy,
+template <typename T>
+static int symm_matmat_wide_impl(const T* Kp, int64_t n, int64_t first, int64_t stride, const T* V,
+                                 int64_t k, int64_t ldv, double alpha, double shift, T* Y, int64_t ldy,
                                  void* ws, size_t ws_bytes, hipStream_t st) {
-    const SymLayout L = make_layout<float>(n, first, stride);
+    const SymLayout L = make_layout<T>(n, first, stride);
     const int64_t T_loc = L.strips_local();
     const int64_t max_items = ceil_div(n, ITEM_ROWS);
-    const size_t need = symm_wide_ws_bytes(n, first, stride);
+    const size_t need = symm_wide_ws_bytes<T>(n, first, stride);
     if (ws == nullptr || ws_bytes < need) {
         set_error("rk_symm_matmat: workspace %zu B < required %zu B", ws_bytes, need);
         return RK_ERR_WORKSPACE;
     }
     const int64_t npad = round_up(n, 256);
-    float* Vp = static_cast<float*>(ws);
-    float* Prow = Vp + (size_t)npad * SMK;
-    float* Pcol = Prow + (size_t)L.total_rows() * SMK;
-    hipLaunchKernelGGL(symm_pad_v_kernel, dim3((unsigned)ceil_div(npad * SMK, 256)), dim3(256), 0, st, V, n, npad,
-                       (int)k, ldv, Vp);
+    T* Vp = static_cast<T*>(ws);
+    T* Prow = Vp + (size_t)npad * SMK;
+    T* Pcol = Prow + (size_t)L.total_rows() * SMK;
+    hipLaunchKernelGGL(symm_pad_v_kernel<T>, dim3((unsigned)ceil_div(npad * SMK, 256)), dim3(256), 0, st, V, n,
+                       npad, (int)k, ldv, Vp);
     if (T_loc > 0) {
         int64_t total_items = 0;
         for (int64_t t = 0; t < T_loc; ++t) total_items += ceil_div(L.rows(t), ITEM_ROWS);
-        // rows per tile: 32 (default; 17.9 ms at n = 200 000, k = 10) or RK_SYMM_TR=16 (4 workgroups per
-        // CU instead of 2: 18.7 ms - the barrier per 16 KiB costs more than the occupancy gains)
-        const char* e = getenv("RK_SYMM_TR");
-        const bool tr16 = e != nullptr && e[0] == '1';
-        int rcl = tr16 ? launch_symm_mfma<16>(Kp, L, Vp, Prow, Pcol, max_items, total_items, st)
-                       : launch_symm_mfma<32>(Kp, L, Vp, Prow, Pcol, max_items, total_items, st);
+        int rcl;
+        if constexpr (sizeof(T) == 4) {
+            // rows per tile: 32 (default; 17.9 ms at n = 200 000, k = 10) or RK_SYMM_TR=16 (4 workgroups per
+            // CU instead of 2: 18.7 ms - the barrier per 16 KiB costs more than the occupancy gains)
+            const char* e = getenv("RK_SYMM_TR");
+            const bool tr16 = e != nullptr && e[0] == '1';
+            rcl = tr16 ? launch_symm_mfma<T, 16>(Kp, L, Vp, Prow, Pcol, max_items, total_items, st)
+                       : launch_symm_mfma<T, 32>(Kp, L, Vp, Prow, Pcol, max_items, total_items, st);
+        } else {
+            rcl = launch_symm_mfma<T, 16>(Kp, L, Vp, Prow, Pcol, max_items, total_items, st);
+        }
         if (rcl != RK_OK) return rcl;
         int rc = launch_status("rk_symm_matmat(wide)");
         if (rc != RK_OK) return rc;
     }
-    hipLaunchKernelGGL((symm_finish_kernel<float>), dim3((unsigned)ceil_div(n * k, 64)), dim3(1024), 0, st, L,
-                       (int)k, SMK, Prow, Pcol, max_items, (float)alpha, (float)shift, V, ldv, Y, ldy);
+    hipLaunchKernelGGL((symm_finish_kernel<T>), dim3((unsigned)ceil_div(n * k, 64)), dim3(1024), 0, st, L,
+                       (int)k, SMK, Prow, Pcol, max_items, (T)alpha, (T)shift, V, ldv, Y, ldy);
     return launch_status("rk_symm_matmat(finish)");
 }
 
 }  // namespace rk
 
 using namespace rk;
+
+// the matrix-core strip kernel takes 5 .. 16 right-hand sides, and float64 from 4 on (the float64 register
+// kernel streams 3.7 TB/s at k = 4: 21.3 ms against 19.4 ms at n = 140 000)
+static bool symm_use_wide(int dtype, int store_dtype, int64_t k) {
+    if (store_dtype != dtype) return false;
+    if (k > 4) return true;
+    if (k < 4 || dtype != RK_F64) return false;
+    const char* e = getenv("RK_SYMM_WIDE");  // (0: the register kernel also at float64 k = 4)
+    return !(e != nullptr && e[0] == '0');
+}
 
 static int check_layout(const char* fn, int dtype, int store_dtype, int64_t n, int64_t first,
                         int64_t stride) {
@@ -762,9 +815,12 @@ extern "C" int rk_kernel_materialize_sympack(int dtype, int store_dtype, int kin
 extern "C" size_t rk_symm_matmat_ws_bytes(int dtype, int store_dtype, int64_t n, int64_t k,
                                           int64_t strip_first, int64_t strip_stride) {
     if (n <= 0 || k < 1 || strip_stride < 1 || strip_first < 0 || strip_first >= strip_stride) return 0;
-    if (k > 4)
-        return (k <= SMK && dtype == RK_F32 && store_dtype == RK_F32)
-                   ? symm_wide_ws_bytes(n, strip_first, strip_stride) : 0;
+    if (symm_use_wide(dtype, store_dtype, k)) {
+        if (k > SMK) return 0;
+        return dtype == RK_F32 ? symm_wide_ws_bytes<float>(n, strip_first, strip_stride)
+                               : symm_wide_ws_bytes<double>(n, strip_first, strip_stride);
+    }
+    if (k > 4) return 0;
     if (dtype == RK_F32) return symm_ws_bytes<float, float>(n, k, strip_first, strip_stride);
     return store_dtype == RK_F32 ? symm_ws_bytes<float, double>(n, k, strip_first, strip_stride)
                                  : symm_ws_bytes<double, double>(n, k, strip_first, strip_stride);
@@ -778,16 +834,20 @@ extern "C" int rk_symm_matmat(int dtype, int store_dtype, const void* Kp, int64_
     int rc = check_layout("rk_symm_matmat", dtype, store_dtype, n, strip_first, strip_stride);
     if (rc != RK_OK) return rc;
     RK_REQUIRE(Kp && V && Y, "rk_symm_matmat: null pointer");
-    const bool wide_ok = dtype == RK_F32 && store_dtype == RK_F32;
+    const bool wide_ok = store_dtype == dtype;
     RK_REQUIRE(k >= 1 && k <= (wide_ok ? SMK : 4), "rk_symm_matmat: k=%lld outside [1,%d]", (long long)k,
                wide_ok ? SMK : 4);
     RK_REQUIRE(ldv >= k && ldy >= k, "rk_symm_matmat: leading dimension too small");
     RK_REQUIRE(aligned16(Kp), "rk_symm_matmat: packed matrix must be 16-byte aligned");
     RK_REQUIRE(aligned16(ws), "rk_symm_matmat: workspace must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (k > 4)
-        return symm_matmat_wide_impl((const float*)Kp, n, strip_first, strip_stride, (const float*)V, k, ldv,
-                                     alpha, diag_shift, (float*)Y, ldy, ws, ws_bytes, st);
+    if (symm_use_wide(dtype, store_dtype, k)) {
+        if (dtype == RK_F32)
+            return symm_matmat_wide_impl<float>((const float*)Kp, n, strip_first, strip_stride, (const float*)V, k,
+                                                ldv, alpha, diag_shift, (float*)Y, ldy, ws, ws_bytes, st);
+        return symm_matmat_wide_impl<double>((const double*)Kp, n, strip_first, strip_stride, (const double*)V, k,
+                                             ldv, alpha, diag_shift, (double*)Y, ldy, ws, ws_bytes, st);
+    }
     if (dtype == RK_F32)
         return symm_matmat_impl<float, float>((const float*)Kp, n, strip_first, strip_stride,
                                               (const float*)V, k, ldv, alpha, diag_shift, (float*)Y,

@@ -271,10 +271,10 @@ class HipBackend:
         k = V2.shape[1]
         out = torch.empty((n, k), dtype=V2.dtype, device=dev)
         es = V2.element_size()
-        # float32: 5 .. 16 right-hand sides go through the matrix-core strip kernel in ONE pass over the
-        # packed triangle; otherwise groups of 4 (register kernel)
-        group = 16 if (k > 4 and V2.dtype == torch.float32 and Kp.dtype == torch.float32
-                       and os.environ.get("RK_SYMM_WIDE", "1") != "0") else 4
+        # 5 .. 16 right-hand sides go through the matrix-core strip kernel in ONE pass over the packed
+        # triangle (storage and arithmetic type equal); otherwise groups of 4 (register kernel)
+        wide_from = 4 if V2.dtype == torch.float64 else 5  # (the float64 register kernel is slow at k = 4)
+        group = 16 if (k >= wide_from and V2.dtype == Kp.dtype and os.environ.get("RK_SYMM_WIDE", "1") != "0") else 4
         for c0 in range(0, k, group):
             kc = min(group, k - c0)
             ws, wsn = self._workspace(

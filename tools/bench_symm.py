@@ -19,19 +19,22 @@ def main():
     ap.add_argument("--d", type=int, default=64)
     ap.add_argument("--ks", default="1,4,5,8,10,16")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     be = get_backend()
     n, d = args.n, args.d
     g = torch.Generator().manual_seed(0)
-    X = (torch.randn(n, d, dtype=torch.float64, generator=g) / d**0.5).float().to(dev)
+    dt = torch.float32 if args.dtype == "f32" else torch.float64
+    X = (torch.randn(n, d, dtype=torch.float64, generator=g) / d**0.5).to(dt).to(dev)
     Kp = be.sympack_materialize("rbf", X, 1.0)
-    nbytes = Kp.numel() * 4
+    nbytes = Kp.numel() * Kp.element_size()
     for k in [int(v) for v in args.ks.split(",")]:
-        V = torch.randn(n, k, dtype=torch.float64, generator=g).float().to(dev)
+        V = torch.randn(n, k, dtype=torch.float64, generator=g).to(dt).to(dev)
         rec = {"n": n, "k": k, "packed_GB": round(nbytes / 1e9, 2)}
         outs = {}
-        for mode in (["wide", "wide_tr16", "groups_of_4"] if k > 4 else ["register"]):
+        modes = ["wide", "wide_tr16", "groups_of_4"] if args.dtype == "f32" else ["wide", "groups_of_4"]
+        for mode in (modes if k > 4 else ["register"]):
             os.environ["RK_SYMM_WIDE"] = "0" if mode == "groups_of_4" else "1"
             os.environ["RK_SYMM_TR"] = "16" if mode == "wide_tr16" else "32"
             Y = be.symm_matmat(Kp, n, V)
