@@ -14,11 +14,12 @@ from rlaopt_amd.ops import get_backend
 dev = torch.device("cuda:0")
 be = get_backend()
 m, n = 25_000, 200_000
-A = torch.randn(m, n, device=dev)
+dt = torch.float64 if "--f64" in sys.argv else torch.float32
+A = torch.randn(m, n, device=dev, dtype=dt)
 for k in (1, 2, 3, 4, 5, 8, 9, 10, 12, 16):
-    V = torch.randn(n, k, device=dev)
-    rec = {"m": m, "n": n, "k": k}
-    for mode in (["mfma", "valu_lds"] if k >= 10 else (["register", "valu_lds"] if k in (3, 4) else ["default"])):
+    V = torch.randn(n, k, device=dev, dtype=dt)
+    rec = {"m": m, "n": n, "k": k, "dtype": str(dt)}
+    for mode in (["mfma", "valu_lds"] if (k >= 10 and dt == torch.float32) else (["register", "valu_lds"] if k in (3, 4) else ["default"])):
         os.environ["RK_SKINNY_MFMA"] = "0" if mode == "valu_lds" else "1"
         os.environ["RK_SKINNY_LDS_MIN"] = "3" if mode == "valu_lds" else "5"
         be.matmat(A, V)
@@ -30,7 +31,7 @@ for k in (1, 2, 3, 4, 5, 8, 9, 10, 12, 16):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
-        rec[mode] = {"ms": round(ms, 3), "GBps": round((m * n + n * k + m * k) * 4 / ms / 1e6, 1)}
+        rec[mode] = {"ms": round(ms, 3), "GBps": round((m * n + n * k + m * k) * A.element_size() / ms / 1e6, 1)}
     os.environ["RK_SKINNY_MFMA"] = "1"
     os.environ["RK_SKINNY_LDS_MIN"] = "5"
     print(json.dumps(rec), flush=True)
