@@ -625,6 +625,26 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
     def blk_oracle(self, blk: torch.Tensor) -> _DistributedLinOp:
         """K(A1[blk], A2[blk]): row-distributed over chunks of blk (base.py:449-505)."""
         be = get_backend()
+        es = torch.empty((), dtype=self.dtype).element_size()
+        if (self._spmd and 0 < blk.shape[0] ** 2 * es <= _BLK_MATERIALIZE_BYTES
+                and os.environ.get("RK_SAP_REPLICATE_BLOCK", "1") != "0"):
+            # One rank per GPU and a block that fits: every rank keeps the WHOLE |blk| x |blk| block
+            # (a SAP block is ~100 MB: 90 us to write).  The block preconditioner and the step size of
+            # a SAP step are then rank-local - no collective inside the Nystrom assembly or the power
+            # iteration, and the device-resident power iteration applies - and identical on every rank
+            # (same block, same broadcast sketch seed); only the row-oracle product stays distributed.
+            dev = self._shard_devices[self._rank]
+            cfg = self._kernel_config_devices[dev]
+            Ab = self._A1[blk.to(self._A1.device)].to(dev)
+            Kb = be.kernel_materialize(self._kind, Ab, Ab, cfg.lengthscale, scale=self._scaling)
+
+            def full_matvec(x, Kb=Kb):
+                return be.matmat(Kb, x)
+
+            op = LinOp(device=dev, shape=torch.Size((blk.shape[0], blk.shape[0])), matvec=full_matvec,
+                       matmat=full_matvec, dtype=self.dtype)
+            op._rk_dense = Kb
+            return op
         parts = len(self._shard_devices)
         bounds = _dist.row_chunks(blk.shape[0], parts)
         ops = []
