@@ -681,156 +681,196 @@ struct NNPlan {
 };
 
 // ------------------------------------------------------------------------------------------
-// Y = A V for 5 .. 16 right-hand sides (float32) on the fp32 matrix cores
+// Y = A V for 9 .. 16 right-hand sides on the matrix cores, operands straight from global memory
 // ------------------------------------------------------------------------------------------
 // At 16 right-hand sides the vector units cannot keep up with the HBM stream (16 FMAs per loaded
-// element: the LDS-shared kernel above reaches 2.3 TB/s).  Here a workgroup owns 32 rows and walks a
-// column segment in tiles of 256 columns staged in LDS (32 KiB, double-buffered, two tiles in
-// flight in registers, XOR-swizzled 16-byte chunks - the layout of rk_symm.hip's matrix-core strip
-// kernel, whose row part this is); wave (rb, half) multiplies 16 rows x 128 columns per tile with
-// v_mfma_f32_16x16x4_f32, A operands by ds_read_b128 (4 MFMAs per read), B operands (V of those
-// columns) from a re-packed copy of V in which a lane's 32 values per tile are contiguous.  The
-// accumulator lives across the whole segment; the two column halves are added through LDS once.
-constexpr int MM_K = 16;    // right-hand sides carried
-constexpr int MM_TR = 32;   // rows per workgroup
-constexpr size_t MM_SMEM_BYTES = (2 * MM_TR * 256 + 2 * MM_TR * MM_K) * sizeof(float);
+// element: the LDS-shared kernel above reaches 2.2 TB/s in float32).  v_mfma_*_16x16x4 wants its A
+// operand as lane (row = lane % 16, k = lane / 16): a lane loads 16 bytes of row lane % 16 at byte
+// offset 16 (lane / 16) of the step, so one load instruction fetches 16 rows x 64 bytes and each of its
+// components feeds one MFMA - no LDS, no barrier.  A wave owns 64 rows (four 16-row blocks share the B
+// operands: V of the step's columns, from a re-packed copy in which a lane's values are contiguous)
+// and walks its column segment in steps of 256 bytes per row, three steps in flight in registers
+// (240 of the wave's 512 registers: one wave per SIMD).  The loads are ordinary cached ones: the two
+// halves of a 128-byte line arrive in consecutive instructions and must meet in the vector cache
+// (non-temporal loads: 4.5 TB/s instead of 5.5).  Measured on the 25 000 x 200 000 float32 shard, any
+// 9 <= k <= 16: 5.97 TB/s (2 row blocks per wave: 5.4; 8: 5.8; two steps in flight: 5.7; the previous
+// kernel of this path - 32 x 256 tiles staged in LDS, XOR-swizzled, two tiles in flight - 5.0, and
+// 5.5 with its MFMAs and V loads removed: the global -> register -> LDS -> register hop was the bound).
+constexpr int MM_K = 16;     // right-hand sides carried (k is padded up to it)
+constexpr int MD_RB = 4;     // 16-row blocks per wave
+constexpr int MD_DEPTH = 3;  // steps in flight
+constexpr int MD_ROWS = 64 * MD_RB;  // rows per workgroup (4 waves)
 
-typedef float mm_acc __attribute__((ext_vector_type(4)));
+template <typename T>
+struct MdAcc;
+template <>
+struct MdAcc<float> {
+    typedef float type __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ type mfma(float a, float b, type c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    // accumulator element v of lane group lq = lane / 16 sits in row `row(lq, v)` of the 16 x 16 result
+    static __device__ __forceinline__ int row(int lq, int v) { return 4 * lq + v; }
+};
+template <>
+struct MdAcc<double> {
+    typedef double type __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ type mfma(double a, double b, type c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lq, int v) { return lq + 4 * v; }
+};
 
-// Vq[((T * 2 + half) * 64 + lane) * 32 + 4 s + q] = V[256 T + 128 half + 16 s + 4 (lane / 16) + q][lane % 16]
+// a step = 4 loads of 16 bytes per lane = SC columns; element q of load s of lane (lr, lq) is column
+// SC T + 4 VW s + VW lq + q:  Vd[((T * 4 + s) * 64 + lane) * VW + q] = V[that column][rhs lr]
+template <typename T>
 __global__ void __launch_bounds__(256)
-mm_pack_v_kernel(const float* __restrict__ V, int64_t n, int64_t ntile, int k, int64_t ldv, float* __restrict__ Vq) {
+md_pack_v_kernel(const T* __restrict__ V, int64_t n, int64_t nstep, int k, int64_t ldv, T* __restrict__ Vd) {
+    constexpr int VW = Vec16<T>::N;
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= ntile * 2 * 64 * 32) return;
-    const int sq = (int)(e & 31), lane = (int)((e >> 5) & 63);
-    const int64_t th = e >> 11;  // T * 2 + half
-    const int64_t col = 128 * th + 16 * (sq >> 2) + 4 * (lane >> 4) + (sq & 3);
+    if (e >= nstep * 256 * VW) return;
+    const int q = (int)(e % VW);
+    const int64_t g = e / VW;
+    const int lane = (int)(g & 63), s4 = (int)((g >> 6) & 3);
+    const int64_t t = g >> 8;
+    const int64_t col = (int64_t)16 * VW * t + 4 * VW * s4 + VW * (lane >> 4) + q;
     const int c = lane & 15;
-    Vq[e] = (col < n && c < k) ? V[col * ldv + c] : 0.f;
+    Vd[e] = (col < n && c < k) ? V[col * ldv + c] : T(0);
 }
 
-__device__ __forceinline__ int mm_at(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 2); }
-
-__global__ void __launch_bounds__(256, 2)
-skinny_nn_mfma_kernel(const float* __restrict__ A, int64_t m, int64_t n, int64_t lda, const float* __restrict__ Vq,
-                      float* __restrict__ part, int64_t seg_tiles, int64_t ntile) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* TB = sm;                          // [2][32][256]
-    float* RP = TB + 2 * MM_TR * 256;        // [2 halves][32][16]
+template <typename T>
+__global__ void __launch_bounds__(256, 1)
+skinny_nn_mfma_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda, const T* __restrict__ Vd,
+                      T* __restrict__ part, int64_t seg_steps, int64_t nstep) {
+    using V16 = typename Vec16<T>::type;
+    using Acc = typename MdAcc<T>::type;
+    constexpr int VW = Vec16<T>::N;  // elements per 16-byte load: 4 / 2
+    constexpr int SC = 16 * VW;      // columns per step
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
-    const int rb = wave & 1, half = wave >> 1;
-    const int64_t i0 = (int64_t)blockIdx.x * MM_TR;
-    const int64_t t_lo = (int64_t)blockIdx.y * seg_tiles;
-    const int64_t t_hi = t_lo + seg_tiles < ntile ? t_lo + seg_tiles : ntile;
+    const int64_t i0 = (int64_t)blockIdx.x * MD_ROWS + 16 * MD_RB * wave;
+    if (i0 >= m) return;  // (no barriers in this kernel)
+    const int64_t t_lo = (int64_t)blockIdx.y * seg_steps;
+    const int64_t t_hi = t_lo + seg_steps < nstep ? t_lo + seg_steps : nstep;
     if (t_lo >= t_hi) return;
-    const int64_t t_last = t_hi - 1;
-    // this lane's 4 columns inside a tile; tiles past the matrix edge re-read its last 4 columns, masked.
-    // Two tiles are in flight (register sets A / B, loop unrolled by two).  The V operands of a tile
-    // are requested BEFORE its rows and consumed after them (the wait counter is in order: waiting
-    // for a load that was issued after the tile prefetch would drain the prefetch): they ride in
-    // vinA / vinB and move to vs0 / vs1 when their tile is staged.
-    float4 preA[8], preB[8], vinA[8], vinB[8], vs0[8], vs1[8];
-    auto load_tile = [&](int64_t t, float4 (&pre)[8], float4 (&vin)[8]) {
-        t = t < t_hi ? t : t_last;
-        const float4* vq = reinterpret_cast<const float4*>(Vq + ((t * 2 + half) * 64 + lane) * 32);
+    const T* ar[MD_RB];  // rows past the matrix re-read its last row (their results are not stored)
 #pragma unroll
-        for (int s = 0; s < 8; ++s) vin[s] = vq[s];
-        __builtin_amdgcn_sched_barrier(0);
-        const int64_t col = 256 * t + 4 * lane;
-        const bool in = col < n;  // (n % 4 == 0: a lane's 4 columns are inside or outside together)
-        const int64_t colc = in ? col : n - 4;
+    for (int b = 0; b < MD_RB; ++b) {
+        const int64_t r = i0 + 16 * b + lr < m ? i0 + 16 * b + lr : m - 1;
+        ar[b] = A + r * lda + VW * lq;
+    }
+    const V16* vd = reinterpret_cast<const V16*>(Vd) + lane;
+    // full steps: SC (T + 1) <= n.  The last step of the matrix may be ragged (n % VW == 0): it runs
+    // after the pipelined loop with clamped, zeroed loads.
+    const int64_t t_full = n / SC < t_hi ? n / SC : t_hi;
+    Acc c[MD_RB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int64_t i = i0 + wave + 4 * u;
-            const int64_t ic = i < m ? i : m - 1;
-            pre[u] = load_stream<float4>(A + ic * lda + colc);  // (masked when staged: no use here)
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    for (int b = 0; b < MD_RB; ++b)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) c[b][v] = T(0);
+    struct Step {
+        V16 v[4], x[MD_RB][4];
     };
-    auto store_tile = [&](int buf, int64_t t, const float4 (&pre)[8], const float4 (&vin)[8], float4 (&vs)[8]) {
-        float* tb = TB + buf * MM_TR * 256;
-        t = t < t_hi ? t : t_last;
-        const bool in = 256 * t + 4 * lane < n;
+    // every load of the pipelined loop is unconditional (a step past the end re-reads the last full
+    // one): the compiler then waits with partial vmcnt counts and the queue never drains
+    auto load = [&](int64_t t, Step& st) {
+        t = t < t_full ? t : t_full - 1;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float msk = (in && i0 + wave + 4 * u < m) ? 1.f : 0.f;  // rows / columns past the edge: zeros
-            *reinterpret_cast<float4*>(tb + mm_at(wave + 4 * u, lane)) =
-                make_float4(pre[u].x * msk, pre[u].y * msk, pre[u].z * msk, pre[u].w * msk);
-        }
+        for (int s = 0; s < 4; ++s) st.v[s] = vd[(t * 4 + s) * 64];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) vs[s] = vin[s];
+        for (int b = 0; b < MD_RB; ++b)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) st.x[b][s] = *reinterpret_cast<const V16*>(ar[b] + SC * t + 4 * VW * s);
     };
-    mm_acc crow = {0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](int buf, const float4 (&vb)[8]) {
-        const float* tb = TB + buf * MM_TR * 256;
+    auto fma = [&](const Step& st) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const float4 a = *reinterpret_cast<const float4*>(tb + mm_at(16 * rb + lr, 32 * half + 4 * s + lq));
-            crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, vb[s].x, crow, 0, 0, 0);
-            crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, vb[s].y, crow, 0, 0, 0);
-            crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, vb[s].z, crow, 0, 0, 0);
-            crow = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, vb[s].w, crow, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+            const T* ve = reinterpret_cast<const T*>(&st.v[s]);
+#pragma unroll
+            for (int q = 0; q < VW; ++q)
+#pragma unroll
+                for (int b = 0; b < MD_RB; ++b)
+                    c[b] = MdAcc<T>::mfma(reinterpret_cast<const T*>(&st.x[b][s])[q], ve[q], c[b]);
         }
     };
-    load_tile(t_lo, preA, vinA);
-    store_tile(0, t_lo, preA, vinA, vs0);
-    load_tile(t_lo + 1, preA, vinA);
-    load_tile(t_lo + 2, preB, vinB);
-    __syncthreads();
-    for (int64_t t = t_lo; t < t_hi; t += 2) {
-        store_tile(1, t + 1, preA, vinA, vs1);
-        load_tile(t + 3, preA, vinA);
-        compute(0, vs0);
-        __syncthreads();
-        if (t + 1 < t_hi) {
-            store_tile(0, t + 2, preB, vinB, vs0);
-            load_tile(t + 4, preB, vinB);
-            compute(1, vs1);
-            __syncthreads();
+    if (t_full > t_lo) {
+        Step st[MD_DEPTH];
+#pragma unroll
+        for (int j = 0; j < MD_DEPTH; ++j) load(t_lo + j, st[j]);
+        for (int64_t t = t_lo; t < t_full; t += MD_DEPTH) {
+#pragma unroll
+            for (int j = 0; j < MD_DEPTH; ++j) {
+                if (j == 0 || t + j < t_full) fma(st[j]);
+                load(t + MD_DEPTH + j, st[j]);
+            }
         }
     }
-    // crow[v] = Y[row 16 rb + 4 lq + v][rhs lr] over this wave's column half: add the halves, store
-    float* rp = RP + half * MM_TR * MM_K;
+    if (t_full < t_hi) {  // the ragged step (last segment only, n % SC != 0)
+        const int64_t t = t_full;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) rp[(16 * rb + 4 * lq + v) * MM_K + lr] = crow[v];
-    __syncthreads();
-    for (int e = tid; e < MM_TR * MM_K; e += 256) {
-        const int64_t i = i0 + e / MM_K;
-        if (i < m) part[((int64_t)blockIdx.y * m + i) * MM_K + (e % MM_K)] = RP[e] + RP[MM_TR * MM_K + e];
+        for (int s = 0; s < 4; ++s) {
+            const int64_t col = SC * t + 4 * VW * s + VW * lq;
+            const bool in = col < n;
+            const int64_t cc = (in ? col : n - VW) - VW * lq;  // (ar[] already carries VW lq)
+            const T msk = in ? T(1) : T(0);
+            const V16 v = vd[(t * 4 + s) * 64];
+            const T* ve = reinterpret_cast<const T*>(&v);
+#pragma unroll
+            for (int b = 0; b < MD_RB; ++b) {
+                const V16 x = *reinterpret_cast<const V16*>(ar[b] + cc);
+                const T* xe = reinterpret_cast<const T*>(&x);
+#pragma unroll
+                for (int q = 0; q < VW; ++q) c[b] = MdAcc<T>::mfma(xe[q] * msk, ve[q], c[b]);
+            }
+        }
     }
+    // c[b][v] = Y[row i0 + 16 b + row(lq, v)][rhs lr] over this workgroup's column segment
+#pragma unroll
+    for (int b = 0; b < MD_RB; ++b)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int64_t i = i0 + 16 * b + MdAcc<T>::row(lq, v);
+            if (i < m) part[((int64_t)blockIdx.y * m + i) * MM_K + lr] = c[b][v];
+        }
 }
 
 struct MMPlan {
-    int64_t ntile, S, seg_tiles;
+    int64_t nstep, S, seg_steps;
 };
+template <typename T>
 static MMPlan plan_mm(int64_t m, int64_t n) {
     MMPlan p;
-    p.ntile = ceil_div(n, 256);
-    const int64_t row_blocks = ceil_div(m, MM_TR);
-    int64_t S = ceil_div(4096, row_blocks);  // 512 workgroups are resident: >= 8 rounds
-    if (S > p.ntile / 8) S = p.ntile / 8;    // >= 8 tiles per workgroup
+    p.nstep = ceil_div(n, (int64_t)16 * Vec16<T>::N);
+    const int64_t row_blocks = ceil_div(m, MD_ROWS);
+    int64_t S = 4096 / row_blocks;           // one workgroup per CU is resident: ~16 rounds
+    if (S > p.nstep / 24) S = p.nstep / 24;  // >= 24 steps per wave
     if (S < 1) S = 1;
-    p.seg_tiles = ceil_div(p.ntile, S);
-    p.S = ceil_div(p.ntile, p.seg_tiles);
+    p.seg_steps = ceil_div(p.nstep, S);
+    p.S = ceil_div(p.nstep, p.seg_steps);
     return p;
 }
+template <typename T>
 static size_t mm_ws_bytes(int64_t m, int64_t n) {
-    const MMPlan p = plan_mm(m, n);
-    return ((size_t)p.ntile * 2 * 64 * 32 + (size_t)p.S * m * MM_K) * sizeof(float);
+    const MMPlan p = plan_mm<T>(m, n);
+    return ((size_t)p.nstep * 256 * Vec16<T>::N + (size_t)p.S * m * MM_K) * sizeof(T);
 }
 static bool mm_enabled() {
     const char* e = getenv("RK_SKINNY_MFMA");
     return !(e != nullptr && e[0] == '0');
 }
+// smallest k that takes this kernel: float32 9 (5.9 against 5.1 TB/s of the LDS-shared kernel; at k = 8 that
+// one streams 6.3), float64 7 (5.8 against 4.5 at k = 7, 8; at k = 6: 6.6)
+template <typename T>
+constexpr int64_t mm_min_k() { return sizeof(T) == 4 ? 9 : 7; }
 
-// k <= 4: register kernel (V slice in registers); k >= 5: LDS-shared V slice
-// smallest k that takes the LDS-shared kernel (RK_SKINNY_LDS_MIN overrides it for experiments)
+// k <= 2: register kernel (V slice in registers); k >= 3: LDS-shared V slice (25 000 x 200 000 float32, k = 3 / 4:
+// 6.64 / 6.67 TB/s against 6.46 / 6.05 of the register kernel; float64 alike).  RK_SKINNY_LDS_MIN = 3 .. 5
+// moves the switch for experiments.
 static int64_t lds_min_k() {
     const char* e = getenv("RK_SKINNY_LDS_MIN");
     const int64_t v = e ? atoll(e) : 0;
-    return (v >= 3 && v <= 5) ? v : 5;
+    return (v >= 3 && v <= 5) ? v : 3;
 }
 static int rows_per_wave(int64_t k) {
     if (k >= lds_min_k()) return k <= 8 ? 8 : 4;
@@ -870,43 +910,25 @@ static int matmat_skinny_impl(const T* A, int64_t m, int64_t n, int64_t lda, con
                               double shift, int64_t row0, T* Y, int64_t ldy, void* ws,
                               size_t ws_bytes, hipStream_t st, int dtype) {
     constexpr int VW = Vec16<T>::N;
-    if constexpr (sizeof(T) == 4) {
-        // (measured on the 25 000 x 200 000 shard: the LDS-shared VALU kernel streams 6.6 - 6.2 TB/s at
-        // k = 5 .. 8 and 4.9 at k = 10, 2.2 at k = 16; this kernel 5.0 TB/s at any k)
-        if (k >= 10 && aligned16(A) && lda % 4 == 0 && n % 4 == 0 && n >= 256 && mm_enabled()) {
-            const MMPlan q = plan_mm(m, n);
-            const size_t need = mm_ws_bytes(m, n);
-            if (ws == nullptr || ws_bytes < need) {
-                set_error("rk_matmat_skinny: workspace %zu B < required %zu B", ws_bytes, need);
-                return RK_ERR_WORKSPACE;
-            }
-            float* Vq = static_cast<float*>(ws);
-            float* partq = Vq + (size_t)q.ntile * 2 * 64 * 32;
-            hipLaunchKernelGGL(mm_pack_v_kernel, dim3((unsigned)ceil_div(q.ntile * 4096, 256)), dim3(256), 0, st, V, n,
-                               q.ntile, (int)k, ldv, Vq);
-            static std::atomic<unsigned long long> attr_devs{0};
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            const unsigned long long bit = 1ull << (dev & 63);
-            if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_nn_mfma_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)MM_SMEM_BYTES) != hipSuccess) {
-                    (void)hipGetLastError();
-                    set_error("rk_matmat_skinny: cannot reserve %zu bytes of LDS", MM_SMEM_BYTES);
-                    return RK_ERR_LAUNCH;
-                }
-                attr_devs.fetch_or(bit, std::memory_order_release);
-            }
-            dim3 gridq((unsigned)ceil_div(m, MM_TR), (unsigned)q.S);
-            hipLaunchKernelGGL(skinny_nn_mfma_kernel, gridq, dim3(256), MM_SMEM_BYTES, st, A, m, n, lda, Vq, partq,
-                               q.seg_tiles, q.ntile);
-            int rcq = launch_status("rk_matmat_skinny(mfma)");
-            if (rcq != RK_OK) return rcq;
-            hipLaunchKernelGGL((skinny_nn_finish<float>), dim3((unsigned)ceil_div(m * k, 256)), dim3(256), 0, st, partq,
-                               (int)q.S, m, (int)k, (float)alpha, (float)beta, C, ldc, (float)shift, V, ldv, row0, Y,
-                               ldy, MM_K);
-            return launch_status("rk_matmat_skinny(finish)");
+    if (k >= mm_min_k<T>() && aligned16(A) && lda % VW == 0 && n % VW == 0 && n >= 16 * VW && mm_enabled()) {
+        const MMPlan q = plan_mm<T>(m, n);
+        const size_t need = mm_ws_bytes<T>(m, n);
+        if (ws == nullptr || ws_bytes < need) {
+            set_error("rk_matmat_skinny: workspace %zu B < required %zu B", ws_bytes, need);
+            return RK_ERR_WORKSPACE;
         }
+        T* Vd = static_cast<T*>(ws);
+        T* partq = Vd + (size_t)q.nstep * 256 * VW;
+        hipLaunchKernelGGL((md_pack_v_kernel<T>), dim3((unsigned)ceil_div(q.nstep * 256 * VW, 256)), dim3(256), 0, st, V,
+                           n, q.nstep, (int)k, ldv, Vd);
+        dim3 gridq((unsigned)ceil_div(m, MD_ROWS), (unsigned)q.S);
+        hipLaunchKernelGGL((skinny_nn_mfma_kernel<T>), gridq, dim3(256), 0, st, A, m, n, lda, Vd, partq, q.seg_steps,
+                           q.nstep);
+        int rcq = launch_status("rk_matmat_skinny(mfma)");
+        if (rcq != RK_OK) return rcq;
+        hipLaunchKernelGGL((skinny_nn_finish<T>), dim3((unsigned)ceil_div(m * k, 256)), dim3(256), 0, st, partq, (int)q.S,
+                           m, (int)k, (T)alpha, (T)beta, C, ldc, (T)shift, V, ldv, row0, Y, ldy, MM_K);
+        return launch_status("rk_matmat_skinny(finish)");
     }
     const NNPlan p = plan_nn(dtype, m, n, k);
     const bool vec = aligned16(A) && aligned16(V) && (lda % VW == 0) && (ldv == k);
@@ -932,7 +954,7 @@ static int matmat_skinny_impl(const T* A, int64_t m, int64_t n, int64_t lda, con
                            row0, Y, ldy, vecA);                                                  \
         break;
     const int vecA = aligned16(A) && (lda % VW == 0);
-    if (k >= lds_min_k() && k < 5) {  // (experiment switch: k = 3, 4 through the LDS-shared kernel)
+    if (k >= lds_min_k() && k < 5) {  // k = 3, 4: the LDS-shared kernel (unless RK_SKINNY_LDS_MIN moves the switch)
         switch (k) {
             RK_NN_LDS_CASE(3, 8) RK_NN_LDS_CASE(4, 8)
             default: break;
@@ -1287,8 +1309,8 @@ extern "C" size_t rk_matmat_skinny_ws_bytes(int dtype, int64_t m, int64_t n, int
     const NNPlan p = plan_nn(dtype, m, n, k);
     const size_t es = dtype == RK_F32 ? 4 : 8;
     size_t bytes = p.S > 1 ? (size_t)p.S * m * k * es : 0;
-    if (dtype == RK_F32 && k >= 10 && n >= 256) {  // the matrix-core kernel: re-packed V + partial sums
-        const size_t b = mm_ws_bytes(m, n);
+    if (k >= (dtype == RK_F32 ? mm_min_k<float>() : mm_min_k<double>())) {  // the matrix-core kernel: re-packed V + partial sums
+        const size_t b = dtype == RK_F32 ? mm_ws_bytes<float>(m, n) : mm_ws_bytes<double>(m, n);
         if (b > bytes) bytes = b;
     }
     return bytes;

@@ -545,32 +545,36 @@ def test_sap_update_matches_the_elementwise_formulas(be, prec, accel, eta_on_dev
     assert not be.sap_update(W.T, V, Y, blk, d, e, accel, beta, gamma, alpha)  # non-contiguous: declined
 
 
-@pytest.mark.parametrize("m,n,k", [(33, 256, 10), (1000, 260, 11), (31, 5000, 16), (257, 33000, 13), (4096, 4096, 12)])
-def test_matmat_skinny_matrix_core_kernel(be, monkeypatch, m, n, k):
-    """float32, 10 <= k <= 16, n % 4 == 0: the matrix-core kernel (LDS-staged tiles, re-packed V)
-    against float64 and against the LDS-shared VALU kernel (RK_SKINNY_MFMA=0), with the fused
-    alpha / beta / diag_shift epilogue and a padded leading dimension."""
-    dt = torch.float32
+@pytest.mark.parametrize("dt,m,n,k", [
+    (torch.float32, 33, 256, 10), (torch.float32, 1000, 260, 11), (torch.float32, 31, 5000, 16),
+    (torch.float32, 257, 33000, 13), (torch.float32, 4096, 4096, 12), (torch.float32, 129, 64 * 30 + 4, 9),
+    (torch.float32, 17, 64, 16), (torch.float32, 300, 68, 9),
+    (torch.float64, 33, 256, 10), (torch.float64, 1000, 130, 11), (torch.float64, 31, 5000, 16),
+    (torch.float64, 257, 33002, 13), (torch.float64, 2048, 4096, 9), (torch.float64, 65, 34, 12),
+])
+def test_matmat_skinny_matrix_core_kernel(be, monkeypatch, dt, m, n, k):
+    """9 <= k <= 16, n a multiple of the 16-byte vector: the matrix-core kernel (operands straight from
+    global memory, re-packed V) against float64 on the host and against the LDS-shared VALU kernel
+    (RK_SKINNY_MFMA=0), with the fused alpha / beta / diag_shift epilogue and a padded leading
+    dimension; ragged last steps, fewer rows than a wave owns, one step only."""
     gen = torch.Generator().manual_seed(m + n + k)
     Afull = torch.randn(m, n + 8, dtype=dt, generator=gen)
     A = Afull[:, :n]
-    nv = max(n, m)
     V = torch.randn(n, k, dtype=dt, generator=gen)
     C = torch.randn(m, k, dtype=dt, generator=gen)
     Ad = Afull.to(dev())[:, :n]  # lda = n + 8
-    row0 = 0
     shift = 0.5 if m <= n else 0.0
-    got = be.matmat(Ad, V.to(dev()), alpha=-1.5, beta=0.25, C=C.to(dev()), diag_shift=shift, row0=row0)
-    want = -1.5 * (A.double() @ V.double()) + 0.25 * C.double() + shift * V[:m].double() * (1.0 if shift else 0.0) \
-        if m <= n else -1.5 * (A.double() @ V.double()) + 0.25 * C.double()
+    got = be.matmat(Ad, V.to(dev()), alpha=-1.5, beta=0.25, C=C.to(dev()), diag_shift=shift, row0=0)
+    want = -1.5 * (A.double() @ V.double()) + 0.25 * C.double()
+    if shift:
+        want = want + shift * V[:m].double()
     assert rel_err(got.cpu(), want) < LIM[dt] * 5
     monkeypatch.setenv("RK_SKINNY_MFMA", "0")
-    base = be.matmat(Ad, V.to(dev()), alpha=-1.5, beta=0.25, C=C.to(dev()), diag_shift=shift, row0=row0)
+    base = be.matmat(Ad, V.to(dev()), alpha=-1.5, beta=0.25, C=C.to(dev()), diag_shift=shift, row0=0)
     monkeypatch.delenv("RK_SKINNY_MFMA")
     assert rel_err(got.cpu(), base.cpu().double()) < LIM[dt] * 5
     assert not torch.equal(got, base)  # two different kernels ran
-    assert torch.equal(got, be.matmat(Ad, V.to(dev()), alpha=-1.5, beta=0.25, C=C.to(dev()), diag_shift=shift, row0=row0))
-    del nv
+    assert torch.equal(got, be.matmat(Ad, V.to(dev()), alpha=-1.5, beta=0.25, C=C.to(dev()), diag_shift=shift, row0=0))
 
 
 @pytest.mark.parametrize("kind", ["rbf", "matern52"])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Row-major streaming product ``rk_matmat_skinny`` (the p = 8 shard shape 25 000 x 200 000, float32)
-for 1 .. 16 right-hand sides: ms and GB/s; 5 <= k <= 16 with the matrix-core kernel against the
-LDS-shared VALU kernel (RK_SKINNY_MFMA=0)."""
+for 1 .. 16 right-hand sides: ms and GB/s; 9 <= k <= 16 with the matrix-core kernel against the
+LDS-shared VALU kernel (RK_SKINNY_MFMA=0).  ``--f64``: float64 (a 12 500 x 200 000 shard)."""
 import json
 import os
 import sys
@@ -13,16 +13,18 @@ from rlaopt_amd.ops import get_backend
 
 dev = torch.device("cuda:0")
 be = get_backend()
-m, n = 25_000, 200_000
 dt = torch.float64 if "--f64" in sys.argv else torch.float32
+m, n = (12_500 if dt == torch.float64 else 25_000), 200_000
 A = torch.randn(m, n, device=dev, dtype=dt)
-for k in (1, 2, 3, 4, 5, 8, 9, 10, 12, 16):
+for k in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 16):
     V = torch.randn(n, k, device=dev, dtype=dt)
     rec = {"m": m, "n": n, "k": k, "dtype": str(dt)}
-    for mode in (["mfma", "valu_lds"] if (k >= 10 and dt == torch.float32) else (["register", "valu_lds"] if k in (3, 4) else ["default"])):
+    kmin = 7 if dt == torch.float64 else 9
+    for mode in (["mfma", "valu_lds"] if k >= kmin else (["register", "valu_lds"] if k in (3, 4) else ["default"])):
         os.environ["RK_SKINNY_MFMA"] = "0" if mode == "valu_lds" else "1"
-        os.environ["RK_SKINNY_LDS_MIN"] = "3" if mode == "valu_lds" else "5"
-        be.matmat(A, V)
+        os.environ["RK_SKINNY_LDS_MIN"] = "5" if mode == "register" else "3"
+        for _ in range(3):  # (the first launches after an allocation run at half speed)
+            be.matmat(A, V)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -33,5 +35,5 @@ for k in (1, 2, 3, 4, 5, 8, 9, 10, 12, 16):
         ms = e0.elapsed_time(e1) / 10
         rec[mode] = {"ms": round(ms, 3), "GBps": round((m * n + n * k + m * k) * A.element_size() / ms / 1e6, 1)}
     os.environ["RK_SKINNY_MFMA"] = "1"
-    os.environ["RK_SKINNY_LDS_MIN"] = "5"
+    os.environ["RK_SKINNY_LDS_MIN"] = "3"
     print(json.dumps(rec), flush=True)
