@@ -35,6 +35,9 @@ from .enums import _DampingMode
 from .preconditioner import Preconditioner
 
 
+_FUSED_GRAM_BYTES = 16 << 20
+
+
 def _inv_sqrt_near_identity(G: torch.Tensor) -> torch.Tensor:
     """G^(-1/2) of the r x r float64 Gram matrix G = U^T U of a numerically orthonormal U.  With
     E = G - I small the series I - E/2 + 3E^2/8 - 5E^3/16 + 35E^4/128 is exact to ||E||^5 - three
@@ -61,20 +64,27 @@ class Nystrom(Preconditioner):
         self.low_precision = False
         self.L = None
         self._M = None  # r x r (dense) or length-r (diagonal) apply factor
+        self._raw = False  # True: self.U is the raw sketch image Y (see _update_block)
+        self._rho = None   # this instance's damping once set (the config object is shared and mutable)
+        self._C = None
         self._sharded = False
         self._group = None
 
     # -- assembly ------------------------------------------------------------------------------
-    def _update(self, A, device, before_host_wait=None):
-        """``before_host_wait``: called once, right before the first device -> host read-back (the
-        r x r Gram blocks), i.e. when everything this assembly can do without the host has been
-        queued: a caller with independent device work (SAP's block gradient) launches it there, so
-        that it runs while the host factorises instead of delaying the kernels queued so far."""
+    def _sketch_and_grams(self, A, device, before_host_wait=None):
+        """Y = A Omega (rows of this shard) and the two r x r Gram blocks Omega^T Y, Y^T Y on the host
+        (float64).  ``before_host_wait``: called once, right before the device -> host read-back, i.e.
+        when everything this assembly can do without the host has been queued: a caller with
+        independent device work (SAP's block gradient) launches it there, so that it runs while the
+        host factorises instead of delaying the kernels queued so far."""
         be = get_backend()
         if A.dtype != torch.float64:
             self.low_precision = True
         self._sharded = bool(getattr(A, "is_row_sharded", False))
         self._group = getattr(A, "_group", None)
+        self._raw = False
+        self._C = None
+        self._rho = None
         rank_r = self.config.rank
         sk = get_sketch(self.config.sketch, "right", rank_r, A.shape[1], dtype=A.dtype, device=device)
         Om = sk.Omega_mat
@@ -85,14 +95,28 @@ class Nystrom(Preconditioner):
         else:
             Y = sk._apply_right(A).to(device)
             Om_rows = Om
-        both = torch.stack([be.gram_tn(Om_rows, Y), be.gram_tn(Y, Y)])  # float64 (2, r, r)
+        if Y.numel() * Y.element_size() <= _FUSED_GRAM_BYTES:
+            # a block preconditioner (5 000 x 100): both blocks from one launch, [Omega Y]^T Y
+            both = be.gram_tn(torch.cat([Om_rows, Y], dim=1), Y).view(2, rank_r, rank_r)
+        else:
+            both = torch.stack([be.gram_tn(Om_rows, Y), be.gram_tn(Y, Y)])  # float64 (2, r, r)
         if self._sharded:
             _dist.all_reduce_sum(both, self._group)
         if before_host_wait is not None:
             before_host_wait()
         core, gram = both.cpu()
+        return Y, core, gram
 
-        shift = torch.finfo(A.dtype).eps * torch.trace(core)  # eps of the WORKING dtype
+    def _update(self, A, device, before_host_wait=None):
+        Y, core, gram = self._sketch_and_grams(A, device, before_host_wait)
+        self._finish_spectral(Y, core, gram, A.dtype, device)
+
+    def _finish_spectral(self, Y, core, gram, dtype, device):
+        """U, S of the rank-r approximation from the Gram blocks (the reference's thin SVD of B^T,
+        nystrom.py:94-96, as r x r algebra on the host + two tall GEMMs)."""
+        be = get_backend()
+        rank_r = self.config.rank
+        shift = torch.finfo(dtype).eps * torch.trace(core)  # eps of the WORKING dtype
         core = core + shift * torch.eye(rank_r, dtype=torch.float64)
         with small_host_lapack(rank_r):
             L = torch.linalg.cholesky(core, upper=False)
@@ -106,7 +130,7 @@ class Nystrom(Preconditioner):
             tiny = sigma[0] * 1e-150 if sigma[0] > 0 else 0.0
             inv_sigma = torch.where(sigma > tiny, 1.0 / sigma.clamp_min(1e-300), torch.zeros_like(sigma))
             M = torch.linalg.solve_triangular(L.T.contiguous(), V, upper=True) * inv_sigma[None, :]
-        U = be.gemm(Y, M.to(device=device, dtype=A.dtype))
+        U = be.gemm(Y, M.to(device=device, dtype=dtype))
         del Y
         # one symmetric (Loewdin) re-orthonormalisation: U <- U (U^T U)^-1/2
         G2 = be.gram_tn(U, U)
@@ -114,21 +138,109 @@ class Nystrom(Preconditioner):
             _dist.all_reduce_sum(G2, self._group)
         with small_host_lapack(rank_r):
             fix = _inv_sqrt_near_identity(G2.cpu())
-        self.U = be.gemm(U, fix.to(device=device, dtype=A.dtype))
+        self.U = be.gemm(U, fix.to(device=device, dtype=dtype))
         # (the eigenvalues also stay on the host, rounded to the working dtype: the damping and
         # the apply factor read them without a device round trip)
-        self._S_host = (sig2 - shift).clamp_min(0.0).to(A.dtype)
+        self._S_host = (sig2 - shift).clamp_min(0.0).to(dtype)
         self.S = self._S_host.to(device=device)
         self._M = None
         self.L = None
 
+    def _update_block(self, A, device, baseline_rho: float, before_host_wait=None) -> None:
+        """Assembly AND damping of a preconditioner that will only ever be INVERTED (SAP's block
+        preconditioner, sap.py:64-74), in ONE host round trip and without an eigen-decomposition.
+        With B = Y L^-T (L L^T = Core + shift I) the reference's operator is
+        P = U diag(sigma^2 - shift) U^T + rho I = B f(H) B^T + rho I,  H = B^T B = L^-1 (Y^T Y) L^-T,
+        and every matrix function of H it needs is an r x r solve:
+            P^-1 x = (x - Y M Y^T x) / rho,   M = L^-T (Hs + rho I)^-1 Hs H^-1 L^-1,   Hs = H - shift I,
+            rho    = baseline + lambda_min(Hs)           (adaptive damping, nystrom.py:140-152)
+        so Y itself serves as the basis (``self.U``; NOT orthonormal) and only the smallest eigenvalue
+        is computed.  The spectral route costs the SAP step three host round trips, an r x r
+        eigen-decomposition and two tall GEMMs (1.85 ms at blk = 5 000, r = 100; this one: see
+        DESIGN.md).  Rank-deficient sketches (an eigenvalue the reference would clip to 0), a sharded
+        operator or RK_NYSTROM_BLOCK_FAST=0 take the spectral route."""
+        import os
+
+        Y, core, gram = self._sketch_and_grams(A, device, before_host_wait)
+        if (self._sharded or os.environ.get("RK_NYSTROM_BLOCK_FAST", "1") == "0"
+                or not self._finish_woodbury(Y, core, gram, A.dtype, device, baseline_rho)):
+            self._finish_spectral(Y, core, gram, A.dtype, device)
+            self._update_damping(baseline_rho)
+
+    def _finish_woodbury(self, Y, core, gram, dtype, device, baseline_rho) -> bool:
+        """In Y coordinates (C = Core + shift I, G = Y^T Y, both r x r on the host, float64):
+            M = L^-T (Hs + rho I)^-1 Hs H^-1 L^-1 = N (I - shift C G^-1),   N = (G + (rho - shift) C)^-1
+        so the only use of H = L^-1 G L^-T is its smallest eigenvalue (values only: ``eigvalsh``)."""
+        r = self.config.rank
+        eye = torch.eye(r, dtype=torch.float64)
+        shift = torch.finfo(dtype).eps * torch.trace(core)
+        with small_host_lapack(r):
+            C = core + shift * eye
+            if self.config.damping_mode == _DampingMode.ADAPTIVE:
+                L, info = torch.linalg.cholesky_ex(C, upper=False)
+                if int(info) != 0:
+                    return False
+                H = torch.linalg.solve_triangular(L, gram, upper=False)
+                H = torch.linalg.solve_triangular(L, H.T.contiguous(), upper=False)  # L^-1 G L^-T
+                lam = torch.linalg.eigvalsh(0.5 * (H + H.T))  # ascending
+                lam_min = lam[0] - shift
+                if not bool(lam_min > 1e-13 * lam[-1]):
+                    return False  # the reference clips this direction to 0: spectral route
+                rho = float(baseline_rho + float(lam_min.to(dtype)))
+            else:
+                rho = float(self.config.rho)
+            LG, info = torch.linalg.cholesky_ex(gram)  # (positive definite <=> every sigma^2 > 0)
+            if int(info) != 0:
+                return False
+            LN, info = torch.linalg.cholesky_ex(gram + (rho - shift) * C)
+            if int(info) != 0:
+                return False
+            N = torch.cholesky_inverse(LN)
+            CGinv = torch.cholesky_solve(C, LG).T  # C G^-1
+            M = N - shift * (N @ CGinv)
+            M = 0.5 * (M + M.T)
+            if self.config.damping_mode != _DampingMode.ADAPTIVE:
+                # sigma^2 > shift for every direction (else the reference clips): G - shift C > 0
+                if int(torch.linalg.cholesky_ex(gram - shift * C)[1]) != 0:
+                    return False
+        self.U = Y
+        self._M = M.to(device=device)  # float64: the r x r step is applied in float64
+        self._C = None                 # (P @ x is prepared on first use, see _matmul)
+        self._host_blocks = (C, LG, shift)
+        self._raw = True
+        self.config.rho = rho
+        self._rho = rho
+        self.S = None
+        self._S_host = None
+        self.L = None
+        return True
+
+    def _raw_forward_factor(self):
+        """P = Y (C^-1 - shift G^-1) Y^T + rho I in the raw basis (only P @ x needs it; SAP never does)."""
+        if self._C is None:
+            C, LG, shift = self._host_blocks
+            r = C.shape[0]
+            with small_host_lapack(r):
+                F = torch.linalg.inv(C) - shift * torch.cholesky_inverse(LG)
+            self._C = (0.5 * (F + F.T)).to(device=self.U.device)
+        return self._C
+
     def _update_damping(self, baseline_rho: float) -> None:
         """Adaptive mode: rho = baseline + smallest eigenvalue (nystrom.py:140-152)."""
+        if getattr(self, "_raw", False):
+            raise RuntimeError("Nystrom._update_block already applied the damping")
         if self.config.damping_mode == _DampingMode.ADAPTIVE:
             s_min = self._S_host[-1] if getattr(self, "_S_host", None) is not None else self.S[-1]
             self.config.rho = float(baseline_rho + float(s_min))
+            self._rho = self.config.rho
             self._M = None
             self.L = None
+
+    def _rho_now(self) -> float:
+        """The damping this instance applies.  Like the reference, ``_update_damping`` writes it into
+        the (shared) config (nystrom.py:151-152); SAP prepares the next block preconditioner from the
+        same config object before this one has been applied, so each instance keeps its own copy."""
+        return float(self._rho if self._rho is not None else self.config.rho)
 
     # -- apply ---------------------------------------------------------------------------------
     def _project(self, X, out_f64=False):
@@ -141,14 +253,17 @@ class Nystrom(Preconditioner):
     def _matmul(self, x: torch.Tensor) -> torch.Tensor:
         be = get_backend()
         X = x[:, None] if x.ndim == 1 else x
-        t = self._project(X) * self.S[:, None]
-        out = be.matmat(self.U, t, alpha=1.0, beta=float(self.config.rho), C=X)
+        if getattr(self, "_raw", False):  # P = Y C Y^T + rho I (basis not orthonormal, see _update_block)
+            t = be.matmat(self._raw_forward_factor(), self._project(X, out_f64=True)).to(X.dtype)
+        else:
+            t = self._project(X) * self.S[:, None]
+        out = be.matmat(self.U, t, alpha=1.0, beta=self._rho_now(), C=X)
         return out[:, 0] if x.ndim == 1 else out
 
     def _apply_factor(self):
         if self._M is not None:
             return self._M
-        rho = float(self.config.rho)
+        rho = self._rho_now()
         S64 = (self._S_host if getattr(self, "_S_host", None) is not None else self.S.cpu()).double()
         dev, dt = self.U.device, self.U.dtype
         if self.low_precision:
@@ -176,7 +291,7 @@ class Nystrom(Preconditioner):
         M = self._apply_factor()
         t = self._project(X, out_f64=True)  # r x k, float64
         t = be.matmat(M, t) if M.ndim == 2 else t * M[:, None]
-        inv_rho = 1.0 / float(self.config.rho)
+        inv_rho = 1.0 / self._rho_now()
         out = be.matmat(self.U, t.to(X.dtype), alpha=-inv_rho, beta=inv_rho, C=X)
         return out[:, 0] if unsqueeze else out
 
@@ -195,7 +310,7 @@ class Nystrom(Preconditioner):
             _dist.all_reduce_sum(both, self._group)
         c, xx = both[: r * k].view(r, k), both[r * k :].view(k, k)
         t = be.matmat(M, c) if M.ndim == 2 else c * M[:, None]
-        inv_rho = 1.0 / float(self.config.rho)
+        inv_rho = 1.0 / self._rho_now()
         Z = be.matmat(self.U, t.to(X.dtype), alpha=-inv_rho, beta=inv_rho, C=X)
         XtZ = (xx - c.T @ t) * inv_rho
         return Z, 0.5 * (XtZ + XtZ.T)

@@ -77,10 +77,11 @@ class SAP(Solver):
     def _get_precond(self, blk: torch.Tensor, K_bb=None, before_host_wait=None) -> Preconditioner:
         P = _pf_get_precond(self.precond_config)
         K_bb = self.system.A_blk_oracle(blk) if K_bb is None else K_bb
-        if before_host_wait is not None and isinstance(self.precond_config, NystromConfig):
-            P._update(K_bb, self.device, before_host_wait=before_host_wait)
-        else:
-            P._update(K_bb, self.device)
+        if isinstance(self.precond_config, NystromConfig):
+            # (assembly + damping in one host round trip; the block preconditioner is only ever inverted)
+            P._update_block(K_bb, self.device, self.system.reg, before_host_wait=before_host_wait)
+            return P
+        P._update(K_bb, self.device)
         P._update_damping(baseline_rho=self.system.reg)
         return P
 
@@ -119,7 +120,7 @@ class SAP(Solver):
         v0 = v0.to(device=dense.device, dtype=dt).contiguous().clone()
         if isinstance(blk_precond, Nystrom) and not blk_precond._sharded:
             state = be.power_iteration(dense, self.system.reg, v0, U=blk_precond.U,
-                                       M=blk_precond._apply_factor(), rho=float(blk_precond.config.rho),
+                                       M=blk_precond._apply_factor(), rho=blk_precond._rho_now(),
                                        max_iters=self.power_iters, rtol=1e-3)
         elif isinstance(blk_precond, Identity):
             state = be.power_iteration(dense, self.system.reg, v0, max_iters=self.power_iters, rtol=1e-3)

@@ -92,6 +92,89 @@ def test_nystrom_gram_assembly_matches_reference_svd(dev, prec, case, sketch, mo
         torch.testing.assert_close((P @ x).cpu(), manual, **tol)
 
 
+@pytest.mark.parametrize("case", ["a50", "a300"])
+@pytest.mark.parametrize("sketch", ["gauss", "ortho"])
+@pytest.mark.parametrize("mode", ["adaptive", "non_adaptive"])
+def test_nystrom_block_update_matches_reference(dev, prec, case, sketch, mode):
+    """Nystrom._update_block (SAP's block preconditioner: assembly + damping in one host round trip,
+    no eigen-decomposition, the raw sketch image as basis) gives the REFERENCE's rho, P x and P^-1 x."""
+    g = load_golden(f"nystrom_{prec}")
+    dt = DTYPES[prec]
+    A, x = g[f"{case}_A"].to(dev), g[f"{case}_x"].to(dev)
+    key = f"{case}_{sketch}_{mode}"
+    rho0, base = (1.0, 0.5) if case == "a50" else (1e-6, 1e-6)
+    rank = 20 if case == "a50" else 40
+    P = Nystrom(NystromConfig(rank=rank, rho=rho0, sketch=sketch, damping_mode=mode))
+    with sketches.inject(g[f"{key}_Omega"]):
+        P._update_block(A, dev, base)
+    assert P._raw and P.U.shape == (A.shape[0], rank) and P.U.dtype == dt
+    tol = TOL[dt]
+    assert abs(P.config.rho - float(g[f"{key}_rho"])) <= tol["atol"] + tol["rtol"] * abs(float(g[f"{key}_rho"]))
+    torch.testing.assert_close((P @ x).cpu(), g[f"{key}_Px"], **tol)
+    ref = g[f"{key}_Pinvx"]
+    got = P._inv @ x
+    assert got.shape == x.shape
+    assert (got.cpu() - ref).abs().max() <= tol["rtol"] * ref.abs().max() * 10 + tol["atol"]
+    with pytest.raises(RuntimeError):
+        P._update_damping(base)  # (already folded in)
+    # the switch and the spectral route behind it
+    import os
+
+    os.environ["RK_NYSTROM_BLOCK_FAST"] = "0"
+    try:
+        Q = Nystrom(NystromConfig(rank=rank, rho=rho0, sketch=sketch, damping_mode=mode))
+        with sketches.inject(g[f"{key}_Omega"]):
+            Q._update_block(A, dev, base)
+    finally:
+        del os.environ["RK_NYSTROM_BLOCK_FAST"]
+    assert not Q._raw and Q.S is not None
+    assert abs(Q.config.rho - P.config.rho) <= tol["atol"] + tol["rtol"] * abs(P.config.rho)
+    other = Q._inv @ x
+    assert (got - other).abs().max() <= tol["rtol"] * ref.abs().max() * 10 + tol["atol"]
+
+
+def test_nystrom_block_update_rank_deficient_takes_spectral_route(dev, prec):
+    """A sketch that sees a rank-deficient operator (eigenvalues the reference clips to 0) cannot use
+    the Cholesky-only route: the spectral one runs, on the same sketch."""
+    dt = DTYPES[prec]
+    gen = torch.Generator().manual_seed(5)
+    n, rank = 64, 16
+    F = torch.randn(n, 6, dtype=torch.float64, generator=gen)
+    A = (F @ F.T).to(dt).to(dev)  # rank 6 < 16
+    Om = (torch.randn(rank, n, dtype=torch.float64, generator=gen) / rank**0.5).T.contiguous().to(dt)
+    P = Nystrom(NystromConfig(rank=rank, rho=1e-3, sketch="gauss"))
+    with sketches.inject(Om):
+        P._update_block(A, dev, 1e-3)
+    assert not P._raw and P.S is not None and P.S.shape == (rank,)
+    x = torch.randn(n, dtype=dt, generator=gen).to(dev)
+    assert bool(torch.isfinite(P._inv @ x).all())
+
+
+def test_nystrom_instances_sharing_a_config_keep_their_own_damping(dev, prec):
+    """Adaptive damping writes rho into the config object (as the reference does); two preconditioners
+    built from the SAME config (SAP makes one per step) must each apply their own value."""
+    dt = DTYPES[prec]
+    gen = torch.Generator().manual_seed(9)
+    n, rank = 80, 12
+    cfg = NystromConfig(rank=rank, rho=1e-3, sketch="gauss")
+    ops, pre = [], []
+    for scale in (1.0, 50.0):
+        F = torch.randn(n, n, dtype=torch.float64, generator=gen)
+        A = (scale * (F @ F.T) / n).to(dt).to(dev)
+        P = Nystrom(cfg)
+        P._update(A, dev)
+        P._update_damping(1e-3)
+        ops.append(A)
+        pre.append((P, float(cfg.rho)))
+    assert pre[0][1] != pre[1][1] and cfg.rho == pre[1][1]
+    x = torch.randn(n, dtype=dt, generator=gen).to(dev)
+    for P, rho in pre:
+        assert P._rho_now() == rho
+        back = P @ (P._inv @ x)
+        tol = 1e-9 if dt == torch.float64 else 2e-3
+        assert float((back - x).abs().max() / x.abs().max()) < tol
+
+
 def test_skpre_matches_reference(dev, prec):
     g = load_golden(f"skpre_{prec}")
     dt = DTYPES[prec]

@@ -50,3 +50,4 @@ def test_pcg_tail_graph_replay_matches_eager(monkeypatch):
         out[mode] = (s.W.clone(), s.R.clone(), s.RZ.clone())
     for a, b in zip(out["0"], out["1"]):
         assert torch.equal(a, b)
+
