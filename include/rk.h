@@ -298,6 +298,14 @@ int rk_sparse_sign_apply(int dtype, const void* A, int64_t m, int64_t d, int64_t
 int rk_randn(int dtype, void* out, int64_t rows, int64_t cols, int64_t ld,
              uint64_t seed, uint64_t offset, double scale, void* stream);
 
+/* out[0 .. k) = k DISTINCT integers drawn uniformly from [0, n): the first k images of a keyed
+ * pseudo-random permutation of [0, n) (Feistel network on ceil(log2 n) bits with cycle walking),
+ * reproducible for (n, seed) and independent of k and of the launch geometry (a longer draw
+ * extends a shorter one).  One launch; replaces the block draw
+ * `torch.multinomial(probs, blk_sz, replacement=False)` with uniform probs of rlaopt/solvers/sap.py:76-86
+ * (a uniformly random subset; the reference's generator stream is not reproduced). */
+int rk_sample_distinct(int64_t n, int64_t k, uint64_t seed, int64_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

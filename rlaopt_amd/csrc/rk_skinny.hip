@@ -1515,6 +1515,60 @@ extern "C" int rk_small_solve(int64_t k, int64_t nrhs, const double* A, const do
     return launch_status("rk_small_solve");
 }
 
+// ------------------------------------------------------------------------------------------
+// k distinct uniform draws from [0, n): the head of a pseudo-random permutation
+// ------------------------------------------------------------------------------------------
+// out[i] = pi(i), pi a keyed bijection of [0, n): an alternating Feistel network on the b = ceil(log2 n)
+// bits (left half b / 2 bits, right half the rest; round r XORs one half with a hash of the other - each
+// round is invertible whatever the hash), walked until the image falls below n (a bijection of [0, 2^b)
+// restricted this way is a bijection of [0, n); 2^b < 2 n: fewer than two evaluations on average, and
+// the walk ends because the orbit of i returns to i < n).  One launch of k threads replaces the
+// sort-based `randperm(n)[:k]` (27 kernels, 0.19 - 0.35 ms at n = 500 000) in SAP's block draw.
+__device__ __forceinline__ uint64_t sd_mix(uint64_t x) {  // murmur3's 64-bit finaliser
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+constexpr int SD_ROUNDS = 8;
+
+__global__ void __launch_bounds__(256)
+sample_distinct_kernel(int64_t n, int64_t k, int bits, uint64_t seed, int64_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= k) return;
+    const int cb = bits - bits / 2;  // right half (the larger one when b is odd)
+    const uint64_t mask_l = (1ull << (bits / 2)) - 1, mask_r = (1ull << cb) - 1;
+    uint64_t x = (uint64_t)i;
+    do {
+        uint64_t l = x >> cb, r = x & mask_r;
+#pragma unroll
+        for (int q = 0; q < SD_ROUNDS; ++q) {
+            const uint64_t key = seed + 0x9e3779b97f4a7c15ull * (uint64_t)(q + 1);
+            if (q & 1)
+                r = (r ^ sd_mix(l + key)) & mask_r;
+            else
+                l = (l ^ sd_mix(r + key)) & mask_l;
+        }
+        x = (l << cb) | r;
+    } while (x >= (uint64_t)n);
+    out[i] = (int64_t)x;
+}
+
+extern "C" int rk_sample_distinct(int64_t n, int64_t k, uint64_t seed, int64_t* out, void* stream) {
+    clear_error();
+    RK_REQUIRE(out != nullptr, "rk_sample_distinct: null pointer");
+    RK_REQUIRE(n >= 1 && k >= 1 && k <= n, "rk_sample_distinct: need 1 <= k <= n (k=%lld, n=%lld)", (long long)k,
+               (long long)n);
+    RK_REQUIRE(n <= (1ll << 62), "rk_sample_distinct: n too large");
+    int bits = 2;  // (at least one bit per half)
+    while ((1ll << bits) < n) ++bits;
+    hipLaunchKernelGGL(sample_distinct_kernel, dim3((unsigned)ceil_div(k, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), n, k, bits, seed, out);
+    return launch_status("rk_sample_distinct");
+}
+
 extern "C" int rk_randn(int dtype, void* out, int64_t rows, int64_t cols, int64_t ld, uint64_t seed,
                         uint64_t offset, double scale, void* stream) {
     clear_error();

@@ -578,6 +578,16 @@ class HipBackend:
         _lib.check(rc, "rk_randn")
         return out
 
+    def sample_distinct(self, n, k, device, seed):
+        """k distinct uniform draws from [0, n) (int64, on ``device``): ``rk_sample_distinct``."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("rlaopt_amd: sample_distinct runs on a cuda (ROCm) device only")
+        out = torch.empty((k,), dtype=torch.int64, device=device)
+        rc = self._lib.rk_sample_distinct(int(n), int(k), int(seed) & (2**64 - 1), _ptr(out), _stream(device))
+        _lib.check(rc, "rk_sample_distinct")
+        return out
+
 
 def _device_of(args, kwargs):
     for a in args:
@@ -617,7 +627,8 @@ def _guard_device(fn):
 
 for _name in ("gram_center", "kernel_materialize", "kernel_matmat", "sympack_materialize", "symm_matmat",
               "matmat", "rmatmat", "gemm", "gram_tn", "pcg_update_wr", "pcg_update_p", "axpby_cols",
-              "normal_pass", "small_solve", "sparse_sign_apply", "randn", "power_iteration", "sap_update"):
+              "normal_pass", "small_solve", "sparse_sign_apply", "randn", "sample_distinct", "power_iteration",
+              "sap_update"):
     setattr(HipBackend, _name, _guard_device(getattr(HipBackend, _name)))
 del _name
 

@@ -95,6 +95,14 @@ class SAP(Solver):
         # In an SPMD run every rank must pick the SAME block: the seed comes from rank 0.
         n = self.probs.shape[0]
         seed = int(_dist.broadcast_object(int(torch.randint(0, 2**62, (1,)))))
+        if self._W.is_cuda and os.environ.get("RK_SAP_DRAW", "feistel") != "randperm":
+            from ..ops import get_backend
+
+            be = get_backend()
+            if hasattr(be, "sample_distinct"):
+                # one launch: the head of a keyed pseudo-random permutation of [0, n) (the sort-based
+                # randperm below is 27 launches, 0.19 - 0.35 ms of every step at n = 500 000)
+                return be.sample_distinct(n, self.blk_sz, self._W.device, seed)
         gen = torch.Generator(device=self._W.device)
         gen.manual_seed(seed)
         return torch.randperm(n, device=self._W.device, generator=gen)[: self.blk_sz]

@@ -631,3 +631,70 @@ def test_matrix_free_operator_wide_product_uses_panels(be, monkeypatch, prec):
         M = torch.randn(n, cols, dtype=dt, generator=gen)
         got = A @ M.to(dev())
         assert rel_err(got.cpu(), K @ M.double()) < LIM[dt] * 5, cols
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 16, 17, 1000, 4097, 500_000])
+def test_sample_distinct_is_a_permutation_head(be, n):
+    """rk_sample_distinct: k = n gives every index exactly once (a bijection of [0, n)); a shorter draw
+    is the head of the longer one; the draw depends on the seed and on nothing else."""
+    full = be.sample_distinct(n, n, dev(), seed=12345)
+    assert full.dtype == torch.int64 and full.shape == (n,) and full.is_cuda
+    assert torch.equal(torch.sort(full).values.cpu(), torch.arange(n))
+    k = max(1, n // 100)
+    head = be.sample_distinct(n, k, dev(), seed=12345)
+    assert torch.equal(head, full[:k])
+    assert torch.equal(head, be.sample_distinct(n, k, dev(), seed=12345))
+    if n >= 1000:
+        other = be.sample_distinct(n, n, dev(), seed=12346)
+        assert not torch.equal(other, full)
+        assert float((other == full).float().mean()) < 0.01  # unrelated permutations
+        # not the identity and no drift: a permutation's values are spread evenly over its positions
+        q = full[: n // 4].double()
+        assert abs(float(q.mean()) / (n - 1) - 0.5) < 0.02
+    with pytest.raises((RuntimeError, ValueError)):
+        be.sample_distinct(n, n + 1, dev(), seed=1)
+
+
+def test_sample_distinct_is_uniform_over_seeds(be):
+    """Every index of [0, n) is equally likely to be in the drawn subset, and at each position of it
+    (chi-square over 4 000 seeds, n = 23, k = 6: 22 degrees of freedom, 99.9 % quantile 48.3)."""
+    n, k, seeds = 23, 6, 4000
+    draws = torch.stack([be.sample_distinct(n, k, dev(), seed=1000 + 7 * s) for s in range(seeds)]).cpu()
+    counts = torch.bincount(draws.reshape(-1), minlength=n).double()
+    expect = seeds * k / n
+    assert float(((counts - expect) ** 2 / expect).sum()) < 60.0
+    first = torch.bincount(draws[:, 0], minlength=n).double()
+    assert float(((first - seeds / n) ** 2 / (seeds / n)).sum()) < 60.0
+    # pairs: position 0 and position 1 are not correlated beyond distinctness
+    pair = torch.bincount(draws[:, 0] * n + draws[:, 1], minlength=n * n).double().view(n, n)
+    assert float(pair.diagonal().sum()) == 0
+    off = pair[~torch.eye(n, dtype=torch.bool)]
+    e2 = seeds / (n * (n - 1))
+    assert float(((off - e2) ** 2 / e2).sum()) < 506 + 5 * (2 * 506) ** 0.5  # 505 dof, mean + 5 sigma
+
+
+def test_sap_block_draw_uses_the_device_permutation(be, monkeypatch):
+    """SAP._get_blk on a GPU system: blk_sz distinct indices in one launch, the same block for the same
+    torch seed; RK_SAP_DRAW=randperm restores the sort-based draw."""
+    from rlaopt_amd.kernels import KernelConfig, RBFLinOp
+    from rlaopt_amd.models import LinSys
+    from rlaopt_amd.preconditioners import IdentityConfig
+    from rlaopt_amd.solvers.sap import SAP
+
+    n = 3000
+    g = torch.Generator().manual_seed(1)
+    X = torch.randn(n, 4, generator=g).to(dev())
+    B = torch.randn(n, 1, generator=g).to(dev())
+    A = RBFLinOp(X, X, KernelConfig(lengthscale=1.0))
+    system = LinSys(A, B, reg=1.0, A_row_oracle=A.row_oracle, A_blk_oracle=A.blk_oracle)
+    s = SAP(system, torch.zeros_like(B), IdentityConfig(), dev(), 300, False, None, 5)
+    torch.manual_seed(4)
+    b1 = s._get_blk()
+    torch.manual_seed(4)
+    b2 = s._get_blk()
+    assert b1.is_cuda and b1.dtype == torch.int64 and b1.shape == (300,) and torch.equal(b1, b2)
+    assert torch.unique(b1).numel() == 300 and int(b1.min()) >= 0 and int(b1.max()) < n
+    monkeypatch.setenv("RK_SAP_DRAW", "randperm")
+    torch.manual_seed(4)
+    b3 = s._get_blk()
+    assert torch.unique(b3).numel() == 300 and not torch.equal(b1, b3)
