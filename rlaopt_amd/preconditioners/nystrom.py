@@ -71,7 +71,7 @@ class Nystrom(Preconditioner):
         self._group = None
 
     # -- assembly ------------------------------------------------------------------------------
-    def _sketch_and_grams(self, A, device, before_host_wait=None):
+    def _sketch_and_grams(self, A, device, before_host_wait=None, raw_ortho=False):
         """Y = A Omega (rows of this shard) and the two r x r Gram blocks Omega^T Y, Y^T Y on the host
         (float64).  ``before_host_wait``: called once, right before the device -> host read-back, i.e.
         when everything this assembly can do without the host has been queued: a caller with
@@ -86,7 +86,13 @@ class Nystrom(Preconditioner):
         self._C = None
         self._rho = None
         rank_r = self.config.rank
-        sk = get_sketch(self.config.sketch, "right", rank_r, A.shape[1], dtype=A.dtype, device=device)
+        if raw_ortho:
+            from ..sketches import raw_ortho as _raw
+
+            with _raw():
+                sk = get_sketch(self.config.sketch, "right", rank_r, A.shape[1], dtype=A.dtype, device=device)
+        else:
+            sk = get_sketch(self.config.sketch, "right", rank_r, A.shape[1], dtype=A.dtype, device=device)
         Om = sk.Omega_mat
         if self._sharded:
             lo, hi = A.row_range
@@ -95,7 +101,12 @@ class Nystrom(Preconditioner):
         else:
             Y = sk._apply_right(A).to(device)
             Om_rows = Om
-        if Y.numel() * Y.element_size() <= _FUSED_GRAM_BYTES:
+        if sk.raw:
+            # un-orthonormalised Ortho sketch: Omega^T Omega rides along ([Omega Y]^T [Omega Y], one launch)
+            Z = torch.cat([Om_rows, Y], dim=1)
+            G3 = be.gram_tn(Z, Z)
+            both = torch.stack([G3[:rank_r, rank_r:], G3[rank_r:, rank_r:], G3[:rank_r, :rank_r]])
+        elif Y.numel() * Y.element_size() <= _FUSED_GRAM_BYTES:
             # a block preconditioner (5 000 x 100): both blocks from one launch, [Omega Y]^T Y
             both = be.gram_tn(torch.cat([Om_rows, Y], dim=1), Y).view(2, rank_r, rank_r)
         else:
@@ -104,11 +115,11 @@ class Nystrom(Preconditioner):
             _dist.all_reduce_sum(both, self._group)
         if before_host_wait is not None:
             before_host_wait()
-        core, gram = both.cpu()
-        return Y, core, gram
+        host = both.cpu()
+        return Y, host[0], host[1], (host[2] if sk.raw else None)
 
     def _update(self, A, device, before_host_wait=None):
-        Y, core, gram = self._sketch_and_grams(A, device, before_host_wait)
+        Y, core, gram, _ = self._sketch_and_grams(A, device, before_host_wait)
         self._finish_spectral(Y, core, gram, A.dtype, device)
 
     def _finish_spectral(self, Y, core, gram, dtype, device):
@@ -161,21 +172,46 @@ class Nystrom(Preconditioner):
         operator or RK_NYSTROM_BLOCK_FAST=0 take the spectral route."""
         import os
 
-        Y, core, gram = self._sketch_and_grams(A, device, before_host_wait)
-        if (self._sharded or os.environ.get("RK_NYSTROM_BLOCK_FAST", "1") == "0"
-                or not self._finish_woodbury(Y, core, gram, A.dtype, device, baseline_rho)):
-            self._finish_spectral(Y, core, gram, A.dtype, device)
+        fast = (os.environ.get("RK_NYSTROM_BLOCK_FAST", "1") != "0"
+                and not bool(getattr(A, "is_row_sharded", False)))
+        Y, core, gram, SO = self._sketch_and_grams(
+            A, device, before_host_wait,
+            raw_ortho=fast and self.config.sketch == "ortho" and os.environ.get("RK_NYSTROM_RAW_ORTHO", "1") != "0")
+        if not fast or not self._finish_woodbury(Y, core, gram, A.dtype, device, baseline_rho, SO):
+            if SO is not None:
+                # back to the orthonormal sketch Q = Omega R^-1 (R^T R = Omega^T Omega) the spectral route
+                # assumes: Y, Core and the Gram block transform by R^-1
+                with small_host_lapack(self.config.rank):
+                    R = torch.linalg.cholesky(0.5 * (SO + SO.T), upper=True)
+                    Rinv = torch.linalg.solve_triangular(R, torch.eye(R.shape[0], dtype=torch.float64), upper=True)
+                    core = Rinv.T @ core @ Rinv
+                    gram = Rinv.T @ gram @ Rinv
+                Y = get_backend().gemm(Y, Rinv.to(device=device, dtype=A.dtype))
+            self._finish_spectral(Y, 0.5 * (core + core.T), 0.5 * (gram + gram.T), A.dtype, device)
             self._update_damping(baseline_rho)
 
-    def _finish_woodbury(self, Y, core, gram, dtype, device, baseline_rho) -> bool:
+    def _finish_woodbury(self, Y, core, gram, dtype, device, baseline_rho, SO=None) -> bool:
         """In Y coordinates (C = Core + shift I, G = Y^T Y, both r x r on the host, float64):
             M = L^-T (Hs + rho I)^-1 Hs H^-1 L^-1 = N (I - shift C G^-1),   N = (G + (rho - shift) C)^-1
-        so the only use of H = L^-1 G L^-T is its smallest eigenvalue (values only: ``eigvalsh``)."""
+        so the only use of H = L^-1 G L^-T is its smallest eigenvalue (values only: ``eigvalsh``).
+        ``SO`` = Omega^T Omega of an Ortho sketch left un-orthonormalised (Omega = Q R): every block
+        above transforms by congruence with R (Core_Q = R^-T Core R^-1, ...), the generalized
+        eigenvalues and M R-covariantly, so the orthonormal sketch's result is obtained with
+        shift = eps trace(Core_Q) = eps trace(SO^-1 Core) and C = Core + shift SO - no QR."""
         r = self.config.rank
         eye = torch.eye(r, dtype=torch.float64)
-        shift = torch.finfo(dtype).eps * torch.trace(core)
         with small_host_lapack(r):
-            C = core + shift * eye
+            if SO is None:
+                shift = torch.finfo(dtype).eps * torch.trace(core)
+                C = core + shift * eye
+            else:
+                SO = 0.5 * (SO + SO.T)
+                LS, info = torch.linalg.cholesky_ex(SO)
+                if int(info) != 0:
+                    return False
+                shift = torch.finfo(dtype).eps * torch.trace(torch.cholesky_solve(core, LS))
+                C = core + shift * SO
+            C = 0.5 * (C + C.T)
             if self.config.damping_mode == _DampingMode.ADAPTIVE:
                 L, info = torch.linalg.cholesky_ex(C, upper=False)
                 if int(info) != 0:

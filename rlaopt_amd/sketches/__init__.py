@@ -78,6 +78,23 @@ def inject(*matrices: torch.Tensor):
         _injected.clear()
 
 
+_raw_ortho = [False]
+
+
+@contextlib.contextmanager
+def raw_ortho():
+    """Within the block an ``Ortho`` sketch keeps its Gaussian draw un-orthonormalised and says so
+    (``sk.raw``): a caller whose result depends on range(Omega) only (the block Nystrom
+    preconditioner, which carries Omega^T Omega through its r x r algebra instead) saves the two
+    Cholesky-QR round trips.  Injected matrices are used as given."""
+    prev = _raw_ortho[0]
+    _raw_ortho[0] = True
+    try:
+        yield
+    finally:
+        _raw_ortho[0] = prev
+
+
 def _draw_seed() -> tuple[int, int]:
     pair = torch.randint(0, 2**62, (2,), dtype=torch.int64)  # advances the default CPU generator
     return tuple(int(v) for v in _dist.broadcast_object(pair.tolist()))
@@ -97,6 +114,7 @@ class Sketch(ABC):
         _is_pos_int(sketch_size, "sketch_size")
         want = (self.s, self.d) if self.mode is _SketchSide.LEFT else (self.d, self.s)
         self._sparse = None  # (col int32, sgn int8, row_ptr int64, scale) for sparse-sign sketches
+        self.raw = False     # True: an Ortho sketch left un-orthonormalised (see raw_ortho)
         if _injected:
             Om = _injected.popleft()
             if tuple(Om.shape) != want:
@@ -164,6 +182,9 @@ class Ortho(Sketch):
     def _generate_embedding(self):
         be = get_backend()
         Q = _device_randn(self.d, self.s, self.dtype, self.device)
+        if _raw_ortho[0] and self.mode is _SketchSide.RIGHT:
+            self.raw = True
+            return Q
         for _ in range(2):
             G = be.gram_tn(Q, Q)  # float64 (s x s)
             with small_host_lapack(self.s):

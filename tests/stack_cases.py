@@ -150,6 +150,49 @@ def test_nystrom_block_update_rank_deficient_takes_spectral_route(dev, prec):
     assert bool(torch.isfinite(P._inv @ x).all())
 
 
+@pytest.mark.parametrize("mode", ["adaptive", "non_adaptive"])
+@pytest.mark.parametrize("deficient", [False, True])
+def test_nystrom_block_update_skips_the_qr_of_an_ortho_sketch_exactly(dev, prec, mode, deficient):
+    """sketch="ortho" in Nystrom._update_block: the Gaussian draw is NOT orthonormalised (the result
+    depends on range(Omega) only; Omega^T Omega is carried through the r x r algebra) and rho, P x,
+    P^-1 x equal those of the orthonormalised sketch of the SAME draw (RK_NYSTROM_RAW_ORTHO=0);
+    a rank-deficient operator falls back to the spectral route, on the converted blocks."""
+    import os
+
+    dt = DTYPES[prec]
+    gen = torch.Generator().manual_seed(13)
+    n, rank = 240, 24
+    if deficient:
+        F = torch.randn(n, 10, dtype=torch.float64, generator=gen)
+        A = (F @ F.T / 10).to(dt).to(dev)
+    else:
+        Q, _ = torch.linalg.qr(torch.randn(n, n, dtype=torch.float64, generator=gen))
+        A = ((Q * torch.arange(1, n + 1, dtype=torch.float64) ** -1.5) @ Q.T)
+        A = (0.5 * (A + A.T)).to(dt).to(dev)
+    x = torch.randn(n, 2, dtype=dt, generator=gen).to(dev)
+    got = {}
+    for raw in ("1", "0"):
+        os.environ["RK_NYSTROM_RAW_ORTHO"] = raw
+        try:
+            torch.manual_seed(77)  # the same Gaussian draw both times
+            P = Nystrom(NystromConfig(rank=rank, rho=1e-4, sketch="ortho", damping_mode=mode))
+            P._update_block(A, dev, 1e-4)
+        finally:
+            del os.environ["RK_NYSTROM_RAW_ORTHO"]
+        assert P._raw == (not deficient)
+        if P._raw and raw == "1":  # the basis really is the raw Gaussian image: far from orthonormal
+            G = (P.U.T @ P.U).cpu()
+            assert float((G - torch.eye(rank, dtype=dt)).abs().max()) > 0.5
+        got[raw] = (P._rho_now(), (P @ x).cpu().double(), (P._inv @ x).cpu().double())
+    tol = 1e-8 if dt == torch.float64 else 2e-3
+    assert abs(got["1"][0] - got["0"][0]) <= tol * abs(got["0"][0])
+    for a, b in zip(got["1"][1:], got["0"][1:]):
+        assert bool(torch.isfinite(a).all())
+        if deficient and dt == torch.float32:
+            continue  # (rounding noise / shift is O(1) here: the clipped directions are noise in either route)
+        assert float((a - b).abs().max() / b.abs().max()) < tol
+
+
 def test_nystrom_instances_sharing_a_config_keep_their_own_damping(dev, prec):
     """Adaptive damping writes rho into the config object (as the reference does); two preconditioners
     built from the SAME config (SAP makes one per step) must each apply their own value."""
