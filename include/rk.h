@@ -252,6 +252,17 @@ int rk_gram_small(int dtype, const void* X, int64_t ldx, const void* Y, int64_t 
  * the iteration never reads a scalar back (no reference counterpart: SURVEY 8a row a14). */
 int rk_axpby_cols(int dtype, int64_t n, int64_t k, const void* X, int64_t ldx, const double* a,
                   void* Y, int64_t ldy, const double* b, void* stream);
+/* The n-space half of an LSQR step (Paige & Saunders 1982, section 4, steps 3(b), 4, 5) in one
+ * launch, per column c of a block solve (G, V, W, Y: n x k row-major; scalars: float64 k-vectors on
+ * the device, updated in place):
+ *     v <- g - beta v;  alpha = |v|_2;  v <- v / alpha
+ *     rho = hypot(rhobar, beta);  cs = rhobar / rho;  sn = beta / rho;  theta = sn alpha
+ *     rhobar <- -cs alpha;  phi = cs phibar;  phibar <- sn phibar
+ *     y <- y + (phi / rho) w;  w <- v - (theta / rho) w
+ * No reference counterpart; replaces ~20 element-wise launches per iteration. */
+int rk_lsqr_tail(int dtype, int64_t n, int64_t k, const void* G, int64_t ldg, void* V, int64_t ldv,
+                 void* W, int64_t ldw, void* Y, int64_t ldy, const double* beta, double* rhobar,
+                 double* phibar, double* alpha, void* stream);
 /* One pass over a tall A (m x n, row-major) for BOTH products of a Golub-Kahan / LSQR step:
  *     U  <- A Z - U diag(coef)      (m x k, in place; coef: k float64 scalars on the device)
  *     G   = A^T U_new               (n x k, float64)

@@ -1516,6 +1516,68 @@ extern "C" int rk_small_solve(int64_t k, int64_t nrhs, const double* A, const do
 }
 
 // ------------------------------------------------------------------------------------------
+// the n-space half of an LSQR step in one launch
+// ------------------------------------------------------------------------------------------
+// Per column c (one workgroup each; the columns of a block solve are independent recurrences):
+//     v <- g - beta v;  alpha = |v|;  v <- v / alpha                    (Golub-Kahan, step 3(b))
+//     rho = hypot(rhobar, beta); cs = rhobar / rho; sn = beta / rho; theta = sn alpha
+//     rhobar <- -cs alpha;  phi = cs phibar;  phibar <- sn phibar       (plane rotation, step 4)
+//     y <- y + (phi / rho) w;  w <- v - (theta / rho) w                 (step 5)
+// The vectors have n entries (the columns of A: 512 in BASELINE config 4), so this is pure launch
+// latency: the same arithmetic as ~20 element-wise / reduction launches of 4.5 us each.
+template <typename T>
+__global__ void __launch_bounds__(1024)
+lsqr_tail_kernel(int64_t n, int k, const T* __restrict__ G, int64_t ldg, T* __restrict__ V, int64_t ldv,
+                 T* __restrict__ W, int64_t ldw, T* __restrict__ Y, int64_t ldy, const double* __restrict__ beta,
+                 double* __restrict__ rhobar, double* __restrict__ phibar, double* __restrict__ alpha) {
+    __shared__ double red[16];
+    const int c = blockIdx.x;
+    const double b = beta[c];
+    double ss = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const T x = (T)((double)G[i * ldg + c] - b * (double)V[i * ldv + c]);
+        V[i * ldv + c] = x;  // (rounded to the working dtype before the norm, like the separate launches)
+        ss += (double)x * (double)x;
+    }
+    const double tot = pi_block_sum(ss, red);  // (fixed order; the same value in every thread)
+    const double a = sqrt(tot > 0.0 ? tot : 0.0);
+    const double rb = rhobar[c], pb = phibar[c];
+    const double rho = sqrt(rb * rb + b * b);
+    const double cs = rb / rho, sn = b / rho;
+    const double theta = sn * a, phi = cs * pb;
+    const double cy = phi / rho, cw = -(theta / rho), inva = 1.0 / a;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const T v = (T)((double)V[i * ldv + c] * inva);
+        const T w = W[i * ldw + c];
+        V[i * ldv + c] = v;
+        Y[i * ldy + c] = (T)((double)Y[i * ldy + c] + cy * (double)w);
+        W[i * ldw + c] = (T)((double)v + cw * (double)w);
+    }
+    if (threadIdx.x == 0) {
+        alpha[c] = a;
+        rhobar[c] = -cs * a;
+        phibar[c] = sn * pb;
+    }
+}
+
+extern "C" int rk_lsqr_tail(int dtype, int64_t n, int64_t k, const void* G, int64_t ldg, void* V, int64_t ldv,
+                            void* W, int64_t ldw, void* Y, int64_t ldy, const double* beta, double* rhobar,
+                            double* phibar, double* alpha, void* stream) {
+    clear_error();
+    RK_REQUIRE(dtype == RK_F32 || dtype == RK_F64, "rk_lsqr_tail: bad dtype %d", dtype);
+    RK_REQUIRE(G && V && W && Y && beta && rhobar && phibar && alpha, "rk_lsqr_tail: null pointer");
+    RK_REQUIRE(n >= 1 && k >= 1 && k <= 65535 && ldg >= k && ldv >= k && ldw >= k && ldy >= k, "rk_lsqr_tail: bad shape");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == RK_F32)
+        hipLaunchKernelGGL((lsqr_tail_kernel<float>), dim3((unsigned)k), dim3(1024), 0, st, n, (int)k, (const float*)G, ldg,
+                           (float*)V, ldv, (float*)W, ldw, (float*)Y, ldy, beta, rhobar, phibar, alpha);
+    else
+        hipLaunchKernelGGL((lsqr_tail_kernel<double>), dim3((unsigned)k), dim3(1024), 0, st, n, (int)k, (const double*)G,
+                           ldg, (double*)V, ldv, (double*)W, ldw, (double*)Y, ldy, beta, rhobar, phibar, alpha);
+    return launch_status("rk_lsqr_tail");
+}
+
+// ------------------------------------------------------------------------------------------
 // k distinct uniform draws from [0, n): the head of a pseudo-random permutation
 // ------------------------------------------------------------------------------------------
 // out[i] = pi(i), pi a keyed bijection of [0, n): an alternating Feistel network on the b = ceil(log2 n)

@@ -457,6 +457,26 @@ class HipBackend:
         _lib.check(rc, "rk_axpby_cols")
         return Y
 
+    def lsqr_tail(self, G, V, W, Y, beta, rhobar, phibar):
+        """The n-space half of an LSQR step in one launch (``rk_lsqr_tail``): V, W, Y (n x k, working
+        dtype) and rhobar, phibar (float64 k-vectors) are updated in place; returns alpha (float64 k).
+        None when the operands are not plain row-major device tensors of one dtype."""
+        ok = (G.ndim == 2 and G.shape == V.shape == W.shape == Y.shape and G.dtype == V.dtype == W.dtype == Y.dtype
+              and all(t.is_cuda and t.stride(1) == 1 for t in (G, V, W, Y))
+              and all(t.dtype == torch.float64 and t.is_contiguous() and t.numel() == G.shape[1]
+                      for t in (beta, rhobar, phibar)))
+        if not ok:
+            return None
+        dev = _req(G, V, W, Y, beta, rhobar, phibar)
+        n, k = G.shape
+        alpha = torch.empty(k, dtype=torch.float64, device=dev)
+        rc = self._lib.rk_lsqr_tail(
+            _dt(G), n, k, _ptr(G), G.stride(0), _ptr(V), V.stride(0), _ptr(W), W.stride(0), _ptr(Y), Y.stride(0),
+            _ptr(beta), _ptr(rhobar), _ptr(phibar), _ptr(alpha), _stream(dev),
+        )
+        _lib.check(rc, "rk_lsqr_tail")
+        return alpha
+
     def normal_pass(self, A, Z, U, coef):
         """One pass over the tall A for a Golub-Kahan step: U <- A Z - U diag(coef) in place;
         returns (A^T U_new as float64 n x k, column sums of squares of U_new as float64 k), or
@@ -627,7 +647,7 @@ def _guard_device(fn):
 
 for _name in ("gram_center", "kernel_materialize", "kernel_matmat", "sympack_materialize", "symm_matmat",
               "matmat", "rmatmat", "gemm", "gram_tn", "pcg_update_wr", "pcg_update_p", "axpby_cols",
-              "normal_pass", "small_solve", "sparse_sign_apply", "randn", "sample_distinct", "power_iteration",
+              "normal_pass", "lsqr_tail", "small_solve", "sparse_sign_apply", "randn", "sample_distinct", "power_iteration",
               "sap_update"):
     setattr(HipBackend, _name, _guard_device(getattr(HipBackend, _name)))
 del _name

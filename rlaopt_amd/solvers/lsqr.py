@@ -137,6 +137,14 @@ class LSQR(Solver):
             self._scale(self._Ut, self._Ub, 1.0 / beta)
             # alpha v = Ahat^T u - beta v
             G = self._adjoint(self._Ut, self._Ub)
+        if (hasattr(be, "lsqr_tail") and G.is_cuda and G.dtype == self._V.dtype
+                and os.environ.get("RK_LSQR_FUSED_TAIL", "1") != "0"):
+            # v, alpha, the plane rotation and the y / w updates in one launch (~20 otherwise)
+            beta = beta.contiguous()
+            alpha = be.lsqr_tail(G, self._V, self._Wd, self._Y, beta, self._rhobar, self._phibar)
+            if alpha is not None:
+                self._alpha = alpha
+                return
         be.axpby_cols(G, None, self._V, -beta)
         alpha = self._norms(self._V, None)
         be.axpby_cols(self._V, 1.0 / alpha, self._V)

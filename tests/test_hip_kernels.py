@@ -698,3 +698,36 @@ def test_sap_block_draw_uses_the_device_permutation(be, monkeypatch):
     torch.manual_seed(4)
     b3 = s._get_blk()
     assert torch.unique(b3).numel() == 300 and not torch.equal(b1, b3)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n,k", [(1, 1), (512, 1), (513, 2), (5000, 3)])
+def test_lsqr_tail_matches_the_separate_updates(be, dt, n, k):
+    """rk_lsqr_tail (v, alpha, plane rotation, y and w updates of an LSQR step in one launch) against the
+    same recurrences written out in float64 on the host; views with a padded leading dimension."""
+    g = torch.Generator().manual_seed(n + k)
+    mk = lambda: torch.randn(n, k + 2, dtype=dt, generator=g)  # noqa: E731
+    G0, V0, W0, Y0 = mk(), mk(), mk(), mk()
+    beta = torch.rand(k, dtype=torch.float64, generator=g) + 0.5
+    rhobar = torch.randn(k, dtype=torch.float64, generator=g)
+    phibar = torch.randn(k, dtype=torch.float64, generator=g)
+    Gd, Vd, Wd, Yd = (t.to(dev())[:, :k] for t in (G0, V0, W0, Y0))
+    rb, pb = rhobar.to(dev()), phibar.to(dev())
+    alpha = be.lsqr_tail(Gd, Vd, Wd, Yd, beta.to(dev()), rb, pb)
+    assert alpha is not None and alpha.dtype == torch.float64 and alpha.shape == (k,)
+    G, V, W, Y = (t[:, :k].double() for t in (G0, V0, W0, Y0))
+    v = (G - beta * V).to(dt).double()
+    a = torch.linalg.norm(v, dim=0)
+    v = (v / a).to(dt).double()
+    rho = torch.sqrt(rhobar**2 + beta**2)
+    cs, sn = rhobar / rho, beta / rho
+    theta, phi = sn * a, cs * phibar
+    tol = dict(rtol=2e-6, atol=2e-6) if dt == torch.float32 else dict(rtol=1e-13, atol=1e-13)
+    torch.testing.assert_close(alpha.cpu(), a, rtol=tol["rtol"], atol=0)
+    torch.testing.assert_close(Vd.cpu().double(), v, **tol)
+    torch.testing.assert_close(Yd.cpu().double(), Y + (phi / rho) * W, **tol)
+    torch.testing.assert_close(Wd.cpu().double(), v - (theta / rho) * W, **tol)
+    torch.testing.assert_close(rb.cpu(), -cs * a, rtol=tol["rtol"], atol=0)
+    torch.testing.assert_close(pb.cpu(), sn * phibar, rtol=tol["rtol"], atol=0)
+    if n > 1 and k > 1:  # column-major G: declined
+        assert be.lsqr_tail(Gd.T.contiguous().T, Vd, Wd, Yd, beta.to(dev()), rb, pb) is None
