@@ -368,6 +368,17 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
                 }
             }
         }
+        // ask the scheduler to alternate matrix-core and vector instructions over the tile's basic block
+        // (the block rows are independent: +2 - 3 % measured; writing the software pipeline out by hand -
+        // the MFMAs of row jb + 1 ahead of the vector half of row jb - gave the same and is not kept)
+        // (not for d > 64: there the hint costs registers the three-workgroup variants do not have)
+        if constexpr (NKS <= 2) {
+#pragma unroll
+            for (int q = 0; q < 128; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            }
+        }
         if (((t - t_lo) & (BX_FOLD_COLS / TJ - 1)) == BX_FOLD_COLS / TJ - 1) {
 #pragma unroll
             for (int ib = 0; ib < 2; ++ib) {
