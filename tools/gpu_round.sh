@@ -6,7 +6,8 @@ TAG=${1:-r01}
 OUT=gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -k 10 600 python -m pytest tests -m gpu -q -x > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest EXIT $?"; tail -3 $OUT/${TAG}_pytest_gpu.log
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/${TAG}_smoke.log 2>&1; tail -1 $OUT/${TAG}_smoke.log
+timeout -k 10 700 python -m pytest tests -m gpu -q -x > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest EXIT $?"; tail -3 $OUT/${TAG}_pytest_gpu.log
 timeout -k 10 300 python bench.py > $OUT/${TAG}_bench_n1.log 2>&1 && echo "bench ok" && tail -1 $OUT/${TAG}_bench_n1.log | cut -c1-400
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o ${TAG} -- python3 bench.py --no-cpu-baseline --no-solve > $OUT/${TAG}_bench_under_rocprof.log 2>&1 && echo "rocprof stats ok"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o ${TAG} -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-solve > $OUT/${TAG}_pmc_fetch.log 2>&1 && echo "pmc fetch ok"
@@ -23,7 +24,7 @@ timeout -k 10 300 python3 tools/bench_kmatmat.py > $OUT/${TAG}_bench_kmatmat.log
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_kmatmat -o ${TAG} -- python3 tools/bench_kmatmat.py --modes bf16x3 --reps 2 --cases 200000x200000x64x1,200000x200000x32x1,5000x500000x50x10g > $OUT/${TAG}_pmc_kmatmat.log 2>&1 && echo "pmc kmatmat ok"
 # many right-hand sides: packed symmetric and row-major streaming kernels
 timeout -k 10 300 python3 tools/bench_symm.py > $OUT/${TAG}_bench_symm.log 2>&1 && echo "symm ok"
-timeout -k 10 300 python3 tools/bench_skinny.py > $OUT/${TAG}_bench_skinny.log 2>&1 && echo "skinny ok"
+timeout -k 10 300 python3 tools/bench_skinny.py > $OUT/${TAG}_bench_skinny.log 2>&1 && timeout -k 10 300 python3 tools/bench_skinny.py --f64 >> $OUT/${TAG}_bench_skinny.log 2>&1 && echo "skinny ok"
 # storage-free PCG (matrix-free operator, symmetric evaluation)
 RK_KERNEL_MODE=matrix_free timeout -k 10 300 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-solve > $OUT/${TAG}_bench_matrix_free.log 2>&1 && echo "matrix-free pcg ok"
 ls -R $OUT | grep -c csv
