@@ -99,3 +99,13 @@ def test_streaming_products_many_columns_random_shapes(be, seed):
     C = torch.randn(m, kk, generator=gen)
     got = be.matmat(Afull.to(DEV)[:, :nn], W.to(DEV), alpha=0.5, beta=-1.0, C=C.to(DEV))
     assert rel_err(got, 0.5 * A.double() @ W.double() - C.double()) < 1e-4 / 2, (m, nn, kk, pad)
+    # the same kernel in float64 (7 .. 16 columns, n % 2 == 0), several row blocks and column segments
+    m = _near(rng, [63, 64, 65, 300, 700], 2)
+    nn = 2 * _near(rng, [16, 33, 2000, 9000, 15000], 3)
+    kk = rng.randint(7, 16)
+    pad = rng.choice([0, 2, 6])
+    Afull = torch.randn(m, nn + pad, dtype=torch.float64, generator=gen)
+    W = torch.randn(nn, kk, dtype=torch.float64, generator=gen)
+    got = be.matmat(Afull.to(DEV)[:, :nn], W.to(DEV), diag_shift=0.25 if m <= nn else 0.0)
+    want = Afull[:, :nn] @ W + (0.25 * W[:m] if m <= nn else 0.0)
+    assert rel_err(got, want) < 1e-13, (m, nn, kk, pad)
