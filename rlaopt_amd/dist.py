@@ -139,3 +139,31 @@ def broadcast_object(obj, src: int = 0, group=None):
     box = [obj]
     td.broadcast_object_list(box, src=src, group=group)
     return box[0]
+
+
+_seed_stream = {"gen": None}
+
+
+def reset_seed_stream() -> None:
+    """Forget the shared seed stream: the next ``shared_randint`` re-bases it on rank 0's default
+    generator (called at the start of every ``solve``, so ``torch.manual_seed`` before a solve decides
+    its draws)."""
+    _seed_stream["gen"] = None
+
+
+def shared_randint(count: int = 1, group=None) -> list[int]:
+    """``count`` integers in [0, 2**62) that every rank agrees on (sketch seeds, SAP's block draw).
+
+    Single process: drawn from torch's default CPU generator.  One rank per GPU: the first call after
+    ``reset_seed_stream`` broadcasts ONE value drawn from rank 0's default generator; it seeds a private
+    generator that all ranks then advance in lockstep (every rank makes the same draws in the same
+    order), so a draw costs no collective - a ``broadcast_object_list`` is two broadcasts and two host
+    round trips, and a SAP step made three of them."""
+    if not spmd_active(group):
+        return [int(v) for v in torch.randint(0, 2**62, (count,), dtype=torch.int64)]
+    if _seed_stream["gen"] is None:
+        base = int(broadcast_object(int(torch.randint(0, 2**62, (1,), dtype=torch.int64)), group=group))
+        gen = torch.Generator()
+        gen.manual_seed(base)
+        _seed_stream["gen"] = gen
+    return [int(v) for v in torch.randint(0, 2**62, (count,), dtype=torch.int64, generator=_seed_stream["gen"])]

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import torch
 
+from .. import dist as _dist
 from ..linops import _is_linop_or_torch_tensor
 from ..ops import get_backend
 from ..solvers import _get_solver, _get_solver_name, _is_solver_config
@@ -104,6 +105,7 @@ class LeastSquares(Model):
         _is_torch_tensor(W_init, "W_init")
         if log_in_wandb and wandb_init_kwargs is None:
             raise ValueError("wandb_init_kwargs must be specified if log_in_wandb is True")
+        _dist.reset_seed_stream()  # (one rank per GPU: this solve's draws follow rank 0's generator as of now)
         atol, rtol = solver_config.atol, solver_config.rtol
         logger = Logger(
             log_freq=callback_freq,

@@ -160,6 +160,7 @@ class LinSys(Model):
         _is_torch_tensor(W_init, "W_init")
         if log_in_wandb and wandb_init_kwargs is None:
             raise ValueError("wandb_init_kwargs must be specified if log_in_wandb is True")
+        _dist.reset_seed_stream()  # (one rank per GPU: this solve's draws follow rank 0's generator as of now)
         atol, rtol = solver_config.atol, solver_config.rtol
         logger = Logger(
             log_freq=callback_freq,

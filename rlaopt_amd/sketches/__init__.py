@@ -96,8 +96,8 @@ def raw_ortho():
 
 
 def _draw_seed() -> tuple[int, int]:
-    pair = torch.randint(0, 2**62, (2,), dtype=torch.int64)  # advances the default CPU generator
-    return tuple(int(v) for v in _dist.broadcast_object(pair.tolist()))
+    # (single process: from the default CPU generator; one rank per GPU: the same pair on every rank)
+    return tuple(_dist.shared_randint(2))
 
 
 def _device_randn(rows: int, cols: int, dtype, device) -> torch.Tensor:

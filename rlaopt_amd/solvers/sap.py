@@ -94,7 +94,7 @@ class SAP(Solver):
         # random permutation on the solver's device (seeded from torch's default generator).
         # In an SPMD run every rank must pick the SAME block: the seed comes from rank 0.
         n = self.probs.shape[0]
-        seed = int(_dist.broadcast_object(int(torch.randint(0, 2**62, (1,)))))
+        seed = _dist.shared_randint(1)[0]
         if self._W.is_cuda and os.environ.get("RK_SAP_DRAW", "feistel") != "randperm":
             from ..ops import get_backend
 
@@ -143,6 +143,12 @@ class SAP(Solver):
             K_bb = self.system.A_blk_oracle(blk)
         reg = self.system.reg
         v0 = next(self._starts).to(device=self.device, dtype=self._W.dtype) if self._starts else None
+        if v0 is None and _dist.spmd_active():
+            # one rank per GPU: the start vector must be the SAME on every rank (a rank-local
+            # torch.randn, as in spectral_norm.py:16, would give each rank its own step size)
+            from ..sketches import _device_randn
+
+            v0 = _device_randn(self.blk_sz, 1, self._W.dtype, self.device)[:, 0]
         eta = self._fused_stepsize(K_bb, blk_precond, v0)
         if eta is not None:
             return eta

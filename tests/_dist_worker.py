@@ -225,6 +225,30 @@ def main():
         finally:
             _t.set_default_dtype(_old)
         torch.testing.assert_close(Wsap, ref.W, rtol=1e-8, atol=1e-10)
+        # ---- the same solve with its own draws (blocks, Ortho sketches, start vectors): the ranks'
+        # generators differ, yet every rank ends with the same iterate, and the whole solve costs ONE
+        # object broadcast (the shared seed stream), not three per step -------------------------------
+        count = {"n": 0}
+        real_bcast = td.broadcast_object_list
+
+        def counting(*a, **k):
+            count["n"] += 1
+            return real_bcast(*a, **k)
+
+        td.broadcast_object_list = counting
+        try:
+            torch.manual_seed(500 + rank)
+            scfg2 = SAPConfig(device=cpu, max_iters=steps, atol=0.0, rtol=1e-14,
+                              precond_config=NystromConfig(rank=rk, rho=regs), blk_sz=blk_sz,
+                              accel_config=SAPAccelConfig(mu=regs, nu=10.0))
+            Wown, _ = sysm.solve(scfg2, torch.zeros_like(B), callback_freq=4)
+        finally:
+            td.broadcast_object_list = real_bcast
+        assert count["n"] == 1, count
+        Wsum = Wown.clone()
+        td.all_reduce(Wsum)
+        torch.testing.assert_close(Wsum / size, Wown, rtol=1e-12, atol=1e-12)
+        assert bool(torch.isfinite(Wown).all()) and float(Wown.abs().max()) > 0
     td.barrier()
     if rank == 0:
         print(f"DIST-OK world={size} n={n} iters={max(log)}")
