@@ -118,7 +118,6 @@ constexpr int bx_ldv(int kv) { return (RK_BX_WG3 && kv > 0) ? 4 : BX_LDV; }
 constexpr size_t bx_smem_bytes(int kv) {
     return 2 * BX_IMG + 2 * BX_VROWS * bx_ldv(kv) * sizeof(float) + 2 * BX_VROWS * sizeof(float);
 }
-constexpr size_t BX_SMEM_BYTES = bx_smem_bytes(0);
 constexpr size_t bx_sym_smem_bytes(int kv) {  // + column sums [2][4 waves][64][kv] + 64 dummy slots
     return bx_smem_bytes(kv) + (size_t)(2 * 4 * 64 * kv + 64) * sizeof(float);
 }
@@ -143,7 +142,9 @@ struct BxSym {
     float* pcol;               // [column-table tile][64][KV]
 };
 
-template <bool RBF, int KV, int NKS, bool SYM>
+// KIND: the kernel function at compile time (with a run-time switch in the tile loop the Matern
+// instantiations spilled up to 280 bytes per lane and ran 22 - 93 % slower)
+template <int KIND, int KV, int NKS, bool SYM>
 __global__ void __launch_bounds__(256, ((RK_BX_WG3 && KV > 0 && !SYM) ? 3 : 2))
 kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, const unsigned char* __restrict__ img2,
                           int64_t n1, int64_t n2, float w, float scale, const float* __restrict__ nx,
@@ -152,6 +153,7 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
                           int accumulate, BxSym sym) {
     using G = BxGeo<(NKS <= 2 ? 64 : 128)>;
     constexpr int TJ = G::TJ;
+    constexpr bool RBF = KIND == RK_RBF;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* XB = smem;                                                  // [2][BX_IMG]
     constexpr int LDV = bx_ldv(KV);
@@ -315,7 +317,7 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
                     } else {
                         float s = nxr[ib] + nyv[v] - 2.f * acc[ib][v];
                         s = s > 0.f ? s : 0.f;
-                        p[ib] = kernel_value<float>(kind, s, w);
+                        p[ib] = kernel_value<float>(KIND, s, w);
                     }
                 }
                 const float* vj = vsb + (jb * 16 + 4 * lq + v) * LDV;
@@ -575,8 +577,9 @@ int launch_kmatmat_bf16x3(int kind, const float* X1, int64_t n1, int64_t ldx1, c
         else if (k <= 4) RK_BX(RBFV, 4);                                                        \
         else RK_BX(RBFV, 0);                                                                               \
     } while (0)
-    if (kind == RK_RBF) RK_BX_K(true);
-    else RK_BX_K(false);
+    if (kind == RK_RBF) RK_BX_K(RK_RBF);
+    else if (kind == RK_MATERN32) RK_BX_K(RK_MATERN32);
+    else RK_BX_K(RK_MATERN52);
 #undef RK_BX
 #undef RK_BX_N
 #undef RK_BX_K
@@ -629,8 +632,9 @@ int launch_kmatmat_bf16x3_sym(int kind, const float* X, int64_t n, int64_t ldx, 
         else if (kv == 2) RK_BXS(RBFV, 2);                                                                 \
         else RK_BXS(RBFV, 4);                                                                              \
     } while (0)
-    if (kind == RK_RBF) RK_BXS_K(true);
-    else RK_BXS_K(false);
+    if (kind == RK_RBF) RK_BXS_K(RK_RBF);
+    else if (kind == RK_MATERN32) RK_BXS_K(RK_MATERN32);
+    else RK_BXS_K(RK_MATERN52);
 #undef RK_BXS_K
 #undef RK_BXS
 #undef RK_BXS_N

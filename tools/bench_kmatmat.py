@@ -59,9 +59,14 @@ def main():
         D2 = (A * A).sum(1)[:, None] + (X.double() ** 2).sum(1)[None, :] - 2 * A @ X.double().T
         if args.kind == "rbf":
             Kref = torch.exp(-0.5 * D2.clamp_min(0))
-        else:
+        elif args.kind == "matern32":
             Dm = D2.clamp_min(0).sqrt() * 3**0.5
             Kref = (1 + Dm) * torch.exp(-Dm)
+        elif args.kind == "matern52":
+            D0 = D2.clamp_min(0).sqrt()
+            Kref = (1 + 5**0.5 * D0 + 5.0 / 3.0 * D0 * D0) * torch.exp(-(5**0.5) * D0)
+        else:
+            raise SystemExit("--kind: rbf, matern32 or matern52")
         want = Kref @ V.double()
         rec = {"case": case, "pairs": n1 * n2}
         for mode in args.modes.split(","):
