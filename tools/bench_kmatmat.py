@@ -68,7 +68,7 @@ def main():
         else:
             raise SystemExit("--kind: rbf, matern32 or matern52")
         want = Kref @ V.double()
-        rec = {"case": case, "pairs": n1 * n2}
+        rec = {"case": case, "kind": args.kind, "pairs": n1 * n2}
         for mode in args.modes.split(","):
             set_mode(mode)
             run = lambda: be.kernel_matmat(args.kind, X1, X, 1.0, V, idx1=idx1, gram_center=gc)  # noqa: E731

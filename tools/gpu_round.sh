@@ -21,6 +21,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_lsqr -o ${TAG}_lsqr -- python3 tools/bench_lsqr.py > $OUT/${TAG}_lsqr_under_rocprof.log 2>&1 && echo "rocprof lsqr ok"
 # matrix-free kernel product: the three formulations side by side, then the matrix-core busy counter
 timeout -k 10 300 python3 tools/bench_kmatmat.py > $OUT/${TAG}_bench_kmatmat.log 2>&1 && echo "kmatmat ok" && grep -c Gpair $OUT/${TAG}_bench_kmatmat.log
+timeout -k 10 300 python3 tools/bench_kmatmat.py --kind matern32 --modes bf16x3,direct --cases 100000x100000x64x1,100000x100000x64x4,5000x500000x50x4g,5000x500000x50x10g >> $OUT/${TAG}_bench_kmatmat.log 2>&1 && echo "kmatmat matern ok"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_kmatmat -o ${TAG} -- python3 tools/bench_kmatmat.py --modes bf16x3 --reps 2 --cases 200000x200000x64x1,200000x200000x32x1,5000x500000x50x10g > $OUT/${TAG}_pmc_kmatmat.log 2>&1 && echo "pmc kmatmat ok"
 # many right-hand sides: packed symmetric and row-major streaming kernels
 timeout -k 10 300 python3 tools/bench_symm.py > $OUT/${TAG}_bench_symm.log 2>&1 && echo "symm ok"

@@ -130,7 +130,7 @@ with open(f"{dst}/{tag}_summary.md", "w") as f:
                 continue
             r = json.loads(l)
             g = lambda m, key: r.get(m, {}).get(key, float("nan"))  # noqa: E731
-            f.write(f"| {r['case']} | {g('bf16x3', 'Gpair_s'):.0f} | {g('mfma32', 'Gpair_s'):.0f} | "
+            f.write(f"| {r['case']}{'' if r.get('kind', 'rbf') == 'rbf' else ' ' + r['kind']} | {g('bf16x3', 'Gpair_s'):.0f} | {g('mfma32', 'Gpair_s'):.0f} | "
                     f"{g('direct', 'Gpair_s'):.0f} | {g('bf16x3', 'rel_err_rows'):.1e} / "
                     f"{g('mfma32', 'rel_err_rows'):.1e} / {g('direct', 'rel_err_rows'):.1e} |\n")
         f.write("\n")
