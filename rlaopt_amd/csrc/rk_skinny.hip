@@ -855,9 +855,14 @@ static size_t mm_ws_bytes(int64_t m, int64_t n) {
     const MMPlan p = plan_mm<T>(m, n);
     return ((size_t)p.nstep * 256 * Vec16<T>::N + (size_t)p.S * m * MM_K) * sizeof(T);
 }
-static bool mm_enabled() {
+// RK_SKINNY_MFMA: 0 never, 2 always, otherwise by size: the matrix-core path is three launches (re-pack V,
+// product, fixed-order sum of the column segments), the LDS-shared kernel one or two - below ~16 MB of
+// matrix the launches outweigh the streaming rate (SAP's 5 000 x 100 basis, the 100 x 100 apply factor)
+static bool mm_enabled(int64_t m, int64_t n, size_t elem) {
     const char* e = getenv("RK_SKINNY_MFMA");
-    return !(e != nullptr && e[0] == '0');
+    if (e != nullptr && e[0] == '0') return false;
+    if (e != nullptr && e[0] == '2') return true;
+    return (size_t)m * (size_t)n * elem >= ((size_t)16 << 20);
 }
 // smallest k that takes this kernel: float32 9 (5.9 against 5.1 TB/s of the LDS-shared kernel; at k = 8 that
 // one streams 6.3), float64 7 (5.8 against 4.5 at k = 7, 8; at k = 6: 6.6)
@@ -910,7 +915,7 @@ static int matmat_skinny_impl(const T* A, int64_t m, int64_t n, int64_t lda, con
                               double shift, int64_t row0, T* Y, int64_t ldy, void* ws,
                               size_t ws_bytes, hipStream_t st, int dtype) {
     constexpr int VW = Vec16<T>::N;
-    if (k >= mm_min_k<T>() && aligned16(A) && lda % VW == 0 && n % VW == 0 && n >= 16 * VW && mm_enabled()) {
+    if (k >= mm_min_k<T>() && aligned16(A) && lda % VW == 0 && n % VW == 0 && n >= 16 * VW && mm_enabled(m, n, sizeof(T))) {
         const MMPlan q = plan_mm<T>(m, n);
         const size_t need = mm_ws_bytes<T>(m, n);
         if (ws == nullptr || ws_bytes < need) {

@@ -564,6 +564,7 @@ def test_matmat_skinny_matrix_core_kernel(be, monkeypatch, dt, m, n, k):
     C = torch.randn(m, k, dtype=dt, generator=gen)
     Ad = Afull.to(dev())[:, :n]  # lda = n + 8
     shift = 0.5 if m <= n else 0.0
+    monkeypatch.setenv("RK_SKINNY_MFMA", "2")  # (by default only matrices of 16 MB and more take it)
     got = be.matmat(Ad, V.to(dev()), alpha=-1.5, beta=0.25, C=C.to(dev()), diag_shift=shift, row0=0)
     want = -1.5 * (A.double() @ V.double()) + 0.25 * C.double()
     if shift:
@@ -571,10 +572,14 @@ def test_matmat_skinny_matrix_core_kernel(be, monkeypatch, dt, m, n, k):
     assert rel_err(got.cpu(), want) < LIM[dt] * 5
     monkeypatch.setenv("RK_SKINNY_MFMA", "0")
     base = be.matmat(Ad, V.to(dev()), alpha=-1.5, beta=0.25, C=C.to(dev()), diag_shift=shift, row0=0)
-    monkeypatch.delenv("RK_SKINNY_MFMA")
+    monkeypatch.setenv("RK_SKINNY_MFMA", "2")
     assert rel_err(got.cpu(), base.cpu().double()) < LIM[dt] * 5
     assert not torch.equal(got, base)  # two different kernels ran
     assert torch.equal(got, be.matmat(Ad, V.to(dev()), alpha=-1.5, beta=0.25, C=C.to(dev()), diag_shift=shift, row0=0))
+    monkeypatch.delenv("RK_SKINNY_MFMA")
+    auto = be.matmat(Ad, V.to(dev()), alpha=-1.5, beta=0.25, C=C.to(dev()), diag_shift=shift, row0=0)
+    big = m * n * Ad.element_size() >= 16 << 20
+    assert torch.equal(auto, got if big else base)  # by size: the matrix-core kernel from 16 MB on
 
 
 @pytest.mark.parametrize("kind", ["rbf", "matern52"])

@@ -21,7 +21,7 @@ for k in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 16):
     rec = {"m": m, "n": n, "k": k, "dtype": str(dt)}
     kmin = 7 if dt == torch.float64 else 9
     for mode in (["mfma", "valu_lds"] if k >= kmin else (["register", "valu_lds"] if k in (3, 4) else ["default"])):
-        os.environ["RK_SKINNY_MFMA"] = "0" if mode == "valu_lds" else "1"
+        os.environ["RK_SKINNY_MFMA"] = "0" if mode == "valu_lds" else "2"
         os.environ["RK_SKINNY_LDS_MIN"] = "5" if mode == "register" else "3"
         for _ in range(3):  # (the first launches after an allocation run at half speed)
             be.matmat(A, V)
