@@ -26,6 +26,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUS
 # many right-hand sides: packed symmetric and row-major streaming kernels
 timeout -k 10 300 python3 tools/bench_symm.py > $OUT/${TAG}_bench_symm.log 2>&1 && echo "symm ok"
 timeout -k 10 300 python3 tools/bench_skinny.py > $OUT/${TAG}_bench_skinny.log 2>&1 && timeout -k 10 300 python3 tools/bench_skinny.py --f64 >> $OUT/${TAG}_bench_skinny.log 2>&1 && echo "skinny ok"
+timeout -k 10 200 python3 tools/bench_dense_c1.py > $OUT/${TAG}_bench_dense_c1.log 2>&1 && echo "dense c1 ok" && tail -1 $OUT/${TAG}_bench_dense_c1.log | cut -c1-200
 # storage-free PCG (matrix-free operator, symmetric evaluation)
 RK_KERNEL_MODE=matrix_free timeout -k 10 300 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-solve > $OUT/${TAG}_bench_matrix_free.log 2>&1 && echo "matrix-free pcg ok"
 ls -R $OUT | grep -c csv
