@@ -105,6 +105,18 @@ def committed_traffic(world, n, mode):
     return None if best is None else best["hbm_bytes_per_launch"]
 
 
+
+def _device_info(dev):
+    """Which card this was (the streaming rate differs by up to 5 % from card to card)."""
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        return {"name": p.name, "arch": getattr(p, "gcnArchName", None), "cus": p.multi_processor_count,
+                "clock_mhz": round(getattr(p, "clock_rate", 0) / 1e3) or None,
+                "memory_clock_mhz": round(getattr(p, "memory_clock_rate", 0) / 1e3) or None,
+                "memory_GB": round(p.total_memory / 1e9, 1)}
+    except Exception as e:  # noqa: BLE001 - informational only
+        return {"error": str(e)}
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -330,6 +342,7 @@ def main():
             "matvec_dense_equivalent_GBps_aggregate": (n * n * float(es) / (mv["avg_ms"] * 1e-3) / 1e9) if mv["launches"] else None,
             "rowmajor_shard_product": rowmajor,
             "matrix_free_product": matrix_free,
+            "device": _device_info(dev),
             "setup_materialize_s": round(t_mat, 3),
             "setup_nystrom_s": round(t_pre, 3),
             "rel_res_after_timed_steps": rel_now,
