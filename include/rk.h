@@ -88,6 +88,29 @@ int rk_kernel_matmat(int dtype, int kind,
                      void* Y, int64_t ldy, int accumulate,
                      const void* gram_center, void* ws, size_t ws_bytes, void* stream);
 
+/* The same product for a caller that multiplies by the SAME X2 side again and again (SAP's row
+ * oracle K(X[blk], X) of rlaopt/kernels/base.py:104-128: a new blk, the same X, every step): the
+ * matrix-core formulation first converts both point sets to split bf16 images; with `x2_image`
+ * (device scratch of rk_kernel_x2_image_bytes bytes that the caller keeps between calls) the X2 image
+ * is written there, and a later call with `x2_image_ready` != 0 skips the conversion (96 us of a
+ * 2.5 ms product at n2 = 500 000).  The caller vouches that X2, idx2, d, the lengthscale and
+ * gram_center are those of the call that wrote the image and that the calls are ordered on one
+ * stream.  `*x2_image_valid` (host int, may be NULL) tells whether the image holds the converted
+ * points after this call (0 when another formulation ran: then never pass ready != 0).
+ * x2_image == NULL is rk_kernel_matmat.  rk_kernel_x2_image_bytes returns 0 when no image would
+ * be used (float64, Laplace / Matern-1/2, d > 128, symmetric operands). */
+size_t rk_kernel_x2_image_bytes(int dtype, int kind, int64_t n1, int64_t n2, int64_t d, int64_t k,
+                                int symmetric_operands);
+int rk_kernel_matmat_cached(int dtype, int kind,
+                            const void* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
+                            const void* X2, int64_t n2, int64_t ldx2, const int64_t* idx2,
+                            int64_t d, double ell_scalar, const void* ell_vec, double scale,
+                            const void* V, int64_t k, int64_t ldv,
+                            void* Y, int64_t ldy, int accumulate,
+                            const void* gram_center, void* ws, size_t ws_bytes,
+                            void* x2_image, size_t x2_image_bytes, int x2_image_ready,
+                            int* x2_image_valid, void* stream);
+
 /* `gram_center` (device, length d, same dtype; may be NULL) opts in to the matrix-core
  * formulation of the float32 product (RBF, Matern-3/2, Matern-5/2, d <= 128), which expands
  * |x - y|^2 = |x'|^2 + |y'|^2 - 2 x'.y' with x' = (x - gram_center) / ell.  Its rounding error

@@ -443,6 +443,7 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
 }
 
 size_t bx_aux_bytes(int64_t n1, int64_t n2);
+size_t bx_x2_image_bytes(int64_t n2, int64_t d);
 
 // ---- symmetric products: work list and finishing kernel ------------------------------------------------
 // Row block rb (128 points) owns the 64-point tiles 2 rb .. T - 1, cut into items of `segt` tiles.
@@ -530,6 +531,11 @@ size_t bx_aux_bytes(int64_t n1, int64_t n2) {
     return bx_float_bytes(n1, n2) + (size_t)(round_up(n1, BX_TI) / 32 + round_up(n2, 64) / 32) * BX_IMG;
 }
 int64_t bx_tile_points(int64_t d) { return d <= 64 ? 64 : 32; }
+// a caller-kept image of the X2 side of a product: |y'|^2 of the padded points, then their split images
+size_t bx_x2_image_bytes(int64_t n2, int64_t d) {
+    const int64_t n2pad = round_up(n2, 64);
+    return (size_t)round_up(n2pad * (int64_t)sizeof(float), 256) + (size_t)(n2pad / bx_tile_points(d)) * BX_IMG;
+}
 
 void gram_prep_launch(const float* center, const float* ell_vec, int64_t d, float* iw, float* muw, hipStream_t st);
 
@@ -537,7 +543,7 @@ int launch_kmatmat_bf16x3(int kind, const float* X1, int64_t n1, int64_t ldx1, c
                           const float* X2, int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d, float w,
                           const float* ell_vec, const float* center, float scale, const float* V, int k,
                           int64_t ldv, int64_t S, int64_t tiles_per_seg, void* aux, float* part, float* Y,
-                          int64_t ldy, int accumulate, hipStream_t st) {
+                          int64_t ldy, int accumulate, void* x2_image, int x2_ready, hipStream_t st) {
     const int64_t tj = bx_tile_points(d);
     float* iw = static_cast<float*>(aux);
     float* muw = iw + 128;
@@ -546,17 +552,24 @@ int launch_kmatmat_bf16x3(int kind, const float* X1, int64_t n1, int64_t ldx1, c
     float* nyp = nxp + n1pad;
     unsigned char* img1 = static_cast<unsigned char*>(aux) + bx_float_bytes(n1, n2);
     unsigned char* img2 = img1 + (n1pad / tj) * BX_IMG;
+    if (x2_image != nullptr) {  // caller-kept image of the X2 side: [ |y'|^2 (n2pad) ][ split images ]
+        nyp = static_cast<float*>(x2_image);
+        img2 = static_cast<unsigned char*>(x2_image) + round_up(n2pad * (int64_t)sizeof(float), 256);
+    }
+    const bool split2 = !(x2_image != nullptr && x2_ready);
     gram_prep_launch(center, ell_vec, d, iw, muw, st);
     if (tj == 64) {
         hipLaunchKernelGGL(gram_split_kernel<64>, dim3((unsigned)ceil_div(n1pad * 8, 256)), dim3(256), 0, st, X1,
                            ldx1, idx1, n1, n1pad, d, iw, muw, img1, nxp);
-        hipLaunchKernelGGL(gram_split_kernel<64>, dim3((unsigned)ceil_div(n2pad * 8, 256)), dim3(256), 0, st, X2,
-                           ldx2, idx2, n2, n2pad, d, iw, muw, img2, nyp);
+        if (split2)
+            hipLaunchKernelGGL(gram_split_kernel<64>, dim3((unsigned)ceil_div(n2pad * 8, 256)), dim3(256), 0, st, X2,
+                               ldx2, idx2, n2, n2pad, d, iw, muw, img2, nyp);
     } else {
         hipLaunchKernelGGL(gram_split_kernel<128>, dim3((unsigned)ceil_div(n1pad * 16, 256)), dim3(256), 0, st, X1,
                            ldx1, idx1, n1, n1pad, d, iw, muw, img1, nxp);
-        hipLaunchKernelGGL(gram_split_kernel<128>, dim3((unsigned)ceil_div(n2pad * 16, 256)), dim3(256), 0, st, X2,
-                           ldx2, idx2, n2, n2pad, d, iw, muw, img2, nyp);
+        if (split2)
+            hipLaunchKernelGGL(gram_split_kernel<128>, dim3((unsigned)ceil_div(n2pad * 16, 256)), dim3(256), 0, st, X2,
+                               ldx2, idx2, n2, n2pad, d, iw, muw, img2, nyp);
     }
     const int nks = d <= 32 ? 1 : (d <= 64 ? 2 : 4);
     dim3 grid((unsigned)ceil_div(n1, BX_TI), (unsigned)S);

@@ -664,12 +664,13 @@ static bool kmat_use_gram(int kind, const void* center, int64_t d, int64_t dmax,
 // (three-way bf16 split of every coordinate, six partial products: float32 accuracy at 2.7 x less
 // matrix-core time).  RK_KMAT_BF16X3=0 (read per call) keeps the float32 MFMA kernel.
 size_t bx_aux_bytes(int64_t n1, int64_t n2);
+size_t bx_x2_image_bytes(int64_t n2, int64_t d);
 int64_t bx_tile_points(int64_t d);
 int launch_kmatmat_bf16x3(int kind, const float* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
                           const float* X2, int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d, float w,
                           const float* ell_vec, const float* center, float scale, const float* V, int k,
                           int64_t ldv, int64_t S, int64_t tiles_per_seg, void* aux, float* part, float* Y,
-                          int64_t ldy, int accumulate, hipStream_t st);
+                          int64_t ldy, int accumulate, void* x2_image, int x2_ready, hipStream_t st);
 
 size_t bx_sym_ws_bytes(int64_t n, int64_t k);
 int launch_kmatmat_bf16x3_sym(int kind, const float* X, int64_t n, int64_t ldx, const int64_t* idx, int64_t d,
@@ -729,7 +730,9 @@ static int kmatmat_impl(int kind, const T* X1, int64_t n1, int64_t ldx1, const i
                         const T* X2, int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d,
                         double ell, const T* ell_vec, double scale, const T* V, int64_t k,
                         int64_t ldv, T* Y, int64_t ldy, int accumulate, const T* gram_center, void* ws,
-                        size_t ws_bytes, hipStream_t st) {
+                        size_t ws_bytes, hipStream_t st, void* x2_image = nullptr, size_t x2_image_bytes = 0,
+                        int x2_ready = 0, int* x2_valid = nullptr) {
+    if (x2_valid != nullptr) *x2_valid = 0;  // (set where the image is written or used)
     const T w = ell_vec ? T(1) : T(1.0 / ell);
     if constexpr (sizeof(T) == 4) {
         if (kmat_use_gram(kind, gram_center, d, 64, n1, n2) && kmat_use_bf16x3() && kmat_use_sym() && X1 == X2 &&
@@ -746,9 +749,16 @@ static int kmatmat_impl(int kind, const T* X1, int64_t n1, int64_t ldx1, const i
                 return RK_ERR_WORKSPACE;
             }
             float* partb = pb.S > 1 ? static_cast<float*>(ws) : nullptr;
+            if (x2_image != nullptr && x2_image_bytes < bx_x2_image_bytes(n2, d)) {
+                set_error("rk_kernel_matmat_cached: image buffer %zu B < required %zu B", x2_image_bytes,
+                          bx_x2_image_bytes(n2, d));
+                return RK_ERR_WORKSPACE;
+            }
             int rcb = launch_kmatmat_bf16x3(kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d, (float)w, ell_vec,
                                             gram_center, (float)scale, V, (int)k, ldv, pb.S, pb.tiles_per_seg,
-                                            static_cast<char*>(ws) + off, partb, Y, ldy, accumulate, st);
+                                            static_cast<char*>(ws) + off, partb, Y, ldy, accumulate, x2_image,
+                                            x2_ready, st);
+            if (x2_valid != nullptr && x2_image != nullptr && rcb == RK_OK) *x2_valid = 1;
             if (rcb != RK_OK || partb == nullptr) return rcb;
             hipLaunchKernelGGL((kmat_matmat_finish<T>), dim3((unsigned)ceil_div(n1 * k, 256)), dim3(256),
                                0, st, partb, (int)pb.S, n1, (int)k, (T)scale, Y, ldy, accumulate);
@@ -905,4 +915,39 @@ extern "C" int rk_kernel_matmat(int dtype, int kind, const void* X1, int64_t n1,
                                 idx2, d, ell_scalar, (const double*)ell_vec, scale, (const double*)V,
                                 k, ldv, (double*)Y, ldy, accumulate, (const double*)gram_center, ws,
                                 ws_bytes, st);
+}
+
+extern "C" size_t rk_kernel_x2_image_bytes(int dtype, int kind, int64_t n1, int64_t n2, int64_t d, int64_t k,
+                                           int symmetric_operands) {
+    // only the non-symmetric bf16 matrix-core formulation keeps an image of its X2 side
+    if (dtype != RK_F32 || n2 <= 0 || symmetric_operands) return 0;
+    if (!(kind == RK_RBF || kind == RK_MATERN32 || kind == RK_MATERN52)) return 0;
+    if (d < RK_KMAT_MFMA_DMIN || d > 128 || n2 < 128 || n1 < 1 || k < 1 || k > 16) return 0;
+    return bx_x2_image_bytes(n2, d);
+}
+
+extern "C" int rk_kernel_matmat_cached(int dtype, int kind, const void* X1, int64_t n1, int64_t ldx1,
+                                       const int64_t* idx1, const void* X2, int64_t n2, int64_t ldx2,
+                                       const int64_t* idx2, int64_t d, double ell_scalar, const void* ell_vec,
+                                       double scale, const void* V, int64_t k, int64_t ldv, void* Y, int64_t ldy,
+                                       int accumulate, const void* gram_center, void* ws, size_t ws_bytes,
+                                       void* x2_image, size_t x2_image_bytes, int x2_image_ready,
+                                       int* x2_image_valid, void* stream) {
+    if (x2_image_valid != nullptr) *x2_image_valid = 0;
+    if (dtype != RK_F32 || x2_image == nullptr)
+        return rk_kernel_matmat(dtype, kind, X1, n1, ldx1, idx1, X2, n2, ldx2, idx2, d, ell_scalar, ell_vec, scale,
+                                V, k, ldv, Y, ldy, accumulate, gram_center, ws, ws_bytes, stream);
+    clear_error();
+    int rc = check_kernel_args("rk_kernel_matmat_cached", dtype, kind, X1, n1, ldx1, X2, n2, ldx2, d, ell_scalar,
+                               ell_vec);
+    if (rc != RK_OK) return rc;
+    RK_REQUIRE(V && Y, "rk_kernel_matmat_cached: null pointer");
+    RK_REQUIRE(k >= 1 && k <= 16, "rk_kernel_matmat_cached: k=%lld outside [1,16]", (long long)k);
+    RK_REQUIRE(ldv >= k && ldy >= k, "rk_kernel_matmat_cached: leading dimension too small");
+    RK_REQUIRE(!(X1 == X2 && idx1 == idx2 && n1 == n2),
+               "rk_kernel_matmat_cached: symmetric operands keep no image (use rk_kernel_matmat)");
+    return kmatmat_impl<float>(kind, (const float*)X1, n1, ldx1, idx1, (const float*)X2, n2, ldx2, idx2, d,
+                               ell_scalar, (const float*)ell_vec, scale, (const float*)V, k, ldv, (float*)Y, ldy,
+                               accumulate, (const float*)gram_center, ws, ws_bytes, static_cast<hipStream_t>(stream),
+                               x2_image, x2_image_bytes, x2_image_ready, x2_image_valid);
 }

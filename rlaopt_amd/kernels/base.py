@@ -415,6 +415,7 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
         # base.py:297-302: torch.chunk partition of the rows of A1 (operator) and A2 (oracle)
         self._A1_bounds = _dist.row_chunks(n1, parts)
         self._A2_bounds = _dist.row_chunks(n2, parts)
+        self._row_x2_caches = {}  # chunk index -> converted image of that A2 chunk (row-oracle products)
         self.A1_row_chunks = [torch.arange(lo, hi) for lo, hi in self._A1_bounds]
         self.A2_row_chunks = [torch.arange(lo, hi) for lo, hi in self._A2_bounds]
         if spmd:
@@ -612,9 +613,13 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
             A1b = self._A1[blk.to(self._A1.device)].to(dev)  # gathered once per oracle
             gc = self._gram_center_on(dev)
 
-            def matvec(x, A1b=A1b, A2c=A2c, cfg=cfg, gc=gc):
+            # (every row oracle of this operator multiplies by the same A2 chunk: its converted image is
+            # kept between calls - the chunk, the lengthscale and the centre live as long as the operator)
+            cache = self._row_x2_caches.setdefault(i, {})
+
+            def matvec(x, A1b=A1b, A2c=A2c, cfg=cfg, gc=gc, cache=cache):
                 return be.kernel_matmat(self._kind, A1b, A2c, cfg.lengthscale, x, scale=self._scaling,
-                                        gram_center=gc)
+                                        gram_center=gc, x2_cache=cache)
 
             ops.append(LinOp(device=dev, shape=shape, matvec=matvec, matmat=matvec, dtype=self.dtype))
         return _DistributedLinOp(

@@ -13,6 +13,7 @@ package ever does so by itself.
 from __future__ import annotations
 
 import contextlib
+import ctypes
 import os
 
 import torch
@@ -195,12 +196,14 @@ class HipBackend:
         return center if float(bound) <= _lib.GRAM_MAX_NORM2 else None
 
     def kernel_matmat(self, kind, X1, X2, lengthscale, V, scale=1.0, idx1=None, idx2=None,
-                      gram_center="auto"):
+                      gram_center="auto", x2_cache=None):
         """scale * K(X1[idx1], X2[idx2]) @ V, matrix-free; wide V is processed in
         16-column groups (each group recomputes the kernel entries).  ``gram_center``: the
         tensor returned by :meth:`gram_center` for these point sets (matrix-core formulation),
         None (direct-difference kernels), or "auto" = compute it here (one host read-back per
-        call: operators precompute it instead)."""
+        call: operators precompute it instead).  ``x2_cache``: a dict an operator keeps for ONE
+        (X2, idx2, lengthscale, gram_center) combination it multiplies by repeatedly - the converted
+        image of that point set (``rk_kernel_matmat_cached``) is kept in it between calls."""
         dev, kid, X1, ld1, X2, ld2, ell, ell_vec, idx1, idx2, n1, n2 = self._kernel_common(
             kind, X1, X2, lengthscale, idx1, idx2
         )
@@ -233,6 +236,19 @@ class HipBackend:
                 nbytes = max(nbytes, self._lib.rk_kernel_matmat_sym_ws_bytes(_dt(X1), n1, kc))
             ws, wsn = self._workspace(dev, nbytes)
             es = V2.element_size()
+            img = self._x2_image(x2_cache, dev, kid, X1, X2, ld2, idx2, n1, n2, ell, ell_vec, gram_center, kc, same)
+            if img is not None:
+                buf, ready = img
+                valid = ctypes.c_int(0)
+                rc = self._lib.rk_kernel_matmat_cached(
+                    _dt(X1), kid, _ptr(X1), n1, ld1, _ptr(idx1), _ptr(X2), n2, ld2, _ptr(idx2),
+                    X1.shape[1], ell, _ptr(ell_vec), float(scale), V2.data_ptr() + c0 * es, kc, ldv,
+                    out.data_ptr() + c0 * es, k, 0, _ptr(gram_center), _ptr(ws), wsn, _ptr(buf), buf.numel(),
+                    int(ready), ctypes.byref(valid), _stream(dev),
+                )
+                _lib.check(rc, "rk_kernel_matmat_cached")
+                x2_cache["ready"] = bool(valid.value)
+                continue
             rc = self._lib.rk_kernel_matmat(
                 _dt(X1), kid, _ptr(X1), n1, ld1, _ptr(idx1), _ptr(X2), n2, ld2, _ptr(idx2),
                 X1.shape[1], ell, _ptr(ell_vec), float(scale), V2.data_ptr() + c0 * es, kc, ldv,
@@ -240,6 +256,28 @@ class HipBackend:
             )
             _lib.check(rc, "rk_kernel_matmat")
         return out[:, 0] if squeeze else out
+
+    def _x2_image(self, cache, dev, kid, X1, X2, ld2, idx2, n1, n2, ell, ell_vec, gram_center, kc, same):
+        """(buffer, ready) for ``rk_kernel_matmat_cached`` or None.  The cache is valid for exactly the
+        operands that wrote it and for the stream that did (later calls on that stream are ordered
+        behind the write; any other stream converts again)."""
+        if cache is None or gram_center is None or X1.dtype != torch.float32:
+            return None
+        nbytes = self._lib.rk_kernel_x2_image_bytes(_dt(X1), kid, n1, n2, X1.shape[1], kc, int(bool(same)))
+        if nbytes == 0:
+            return None
+        key = (X2.data_ptr(), n2, ld2, 0 if idx2 is None else idx2.data_ptr(), X1.shape[1], float(ell),
+               0 if ell_vec is None else ell_vec.data_ptr(), gram_center.data_ptr(), kid, dev.index,
+               _stream(dev))
+        buf = cache.get("buf")
+        if buf is None or buf.numel() < nbytes or buf.device != dev:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            cache.update(buf=buf, key=None, ready=False)
+        if cache.get("key") != key:
+            cache.update(key=key, ready=False)
+        # (the arguments above keep X2 / idx2 / the centre alive for the cache's lifetime only through the
+        # operator that owns both: a cache must not outlive its operator)
+        return buf, bool(cache.get("ready"))
 
     # -- symmetric packed kernel matrices ------------------------------------------------------
     def sympack_materialize(self, kind, X, lengthscale, scale=1.0, first=0, stride=1, store_dtype=None):

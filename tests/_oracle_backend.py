@@ -23,7 +23,8 @@ class OracleBackend:
         A2 = X2 if idx2 is None else X2[idx2]
         return ok.kernel_matrix(kind, A1, A2, lengthscale, scale)
 
-    def kernel_matmat(self, kind, X1, X2, lengthscale, V, scale=1.0, idx1=None, idx2=None, gram_center=None):
+    def kernel_matmat(self, kind, X1, X2, lengthscale, V, scale=1.0, idx1=None, idx2=None, gram_center=None,
+                      x2_cache=None):
         return ok.kernel_matmat(kind, X1, X2, lengthscale, V, scale, idx1=idx1, idx2=idx2)
 
     # sympack stand-in: keeps the dense matrix restricted to this rank's strips (upper part)

@@ -736,3 +736,51 @@ def test_lsqr_tail_matches_the_separate_updates(be, dt, n, k):
     torch.testing.assert_close(pb.cpu(), sn * phibar, rtol=tol["rtol"], atol=0)
     if n > 1 and k > 1:  # column-major G: declined
         assert be.lsqr_tail(Gd.T.contiguous().T, Vd, Wd, Yd, beta.to(dev()), rb, pb) is None
+
+
+@pytest.mark.parametrize("kind,d", [("rbf", 50), ("matern32", 64), ("rbf", 100)])
+def test_kernel_matmat_keeps_the_x2_image_between_calls(be, monkeypatch, kind, d):
+    """rk_kernel_matmat_cached: the converted image of the X2 side is written on the first call and reused
+    afterwards (new X1 rows, new V each time) - bitwise the results of the plain entry point; other
+    operands, another formulation or another stream convert again / keep no image."""
+    g = torch.Generator().manual_seed(d)
+    n2, k = 3000, 10
+    X = (torch.randn(n2, d, generator=g) / d**0.5).to(dev())
+    gc = be.gram_center(X, X, 1.0)
+    assert gc is not None
+    cache = {}
+    for step in range(3):
+        blk = torch.randperm(n2, generator=g)[:200].to(dev())
+        V = torch.randn(n2, k, generator=g).to(dev())
+        A1 = X[blk].contiguous()
+        plain = be.kernel_matmat(kind, A1, X, 1.0, V, gram_center=gc)
+        kept = be.kernel_matmat(kind, A1, X, 1.0, V, gram_center=gc, x2_cache=cache)
+        assert torch.equal(plain, kept)
+        assert cache["ready"] is True and cache["buf"].numel() > 0
+        if step == 1:
+            buf_ptr = cache["buf"].data_ptr()
+    assert cache["buf"].data_ptr() == buf_ptr  # (one buffer for the lifetime of the cache)
+    # other operands: converted again, correct again
+    X2 = (X * 0.5).contiguous()
+    V = torch.randn(n2, k, generator=g).to(dev())
+    got = be.kernel_matmat(kind, X[:100].contiguous(), X2, 1.0, V, gram_center=gc, x2_cache=cache)
+    assert torch.equal(got, be.kernel_matmat(kind, X[:100].contiguous(), X2, 1.0, V, gram_center=gc))
+    # another stream: not ordered behind the write - converted again
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        got2 = be.kernel_matmat(kind, X[:100].contiguous(), X2, 1.0, V, gram_center=gc, x2_cache=cache)
+    side.synchronize()
+    assert torch.equal(got2, got)
+    # a formulation without images: nothing is kept
+    monkeypatch.setenv("RK_KMAT_BF16X3", "0")
+    c2 = {}
+    be.kernel_matmat(kind, X[:100].contiguous(), X2, 1.0, V, gram_center=gc, x2_cache=c2)
+    assert c2.get("ready") is False
+    monkeypatch.delenv("RK_KMAT_BF16X3")
+    got3 = be.kernel_matmat(kind, X[:100].contiguous(), X2, 1.0, V, gram_center=gc, x2_cache=c2)
+    assert c2["ready"] is True and torch.equal(got3, got)
+    # symmetric operands and float64 keep no image
+    c3 = {}
+    be.kernel_matmat(kind, X, X, 1.0, V[:, :2].contiguous(), gram_center=gc, x2_cache=c3)
+    assert "buf" not in c3
