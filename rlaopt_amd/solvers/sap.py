@@ -55,6 +55,7 @@ class SAP(Solver):
         self._side = None     # lazily created side stream (see _step)
         self._hi = None
         self._overlap = os.environ.get("RK_SAP_OVERLAP", "1") != "0"
+        self._cols_cache = None  # (mask, active columns on the device, all active?) of the last step
         self._blocks = None   # optional injected block sequence (parity runs)
         self._starts = None   # optional injected power-iteration start vectors
         if accel:
@@ -213,13 +214,21 @@ class SAP(Solver):
 
     def _step_impl(self):
         mask = self.system.mask
-        if not bool(mask.any()):
+        cached = self._cols_cache
+        if cached is None or cached[0].shape != mask.shape or not torch.equal(cached[0], mask):
+            # (the set of active columns changes a handful of times per solve: one host -> device copy then,
+            # not one per step)
+            cached = (mask.clone(), torch.nonzero(mask)[:, 0].to(self._W.device), bool(mask.all()))
+            self._cols_cache = cached
+        _, cols, all_active = cached
+        if cols.numel() == 0:
             return
-        cols = torch.nonzero(mask)[:, 0].to(self._W.device)
         blk = self._get_blk()
         blk_d = blk.to(self._W.device)
         base = self.Y if self.accel else self._W
-        loc = base[:, cols]
+        # all columns active: the iterate and B themselves, not 20 MB copies of them per step
+        loc = base if all_active else base[:, cols]
+        Bc = self.system.B if all_active else self.system.B[:, cols]
         side = self._side_stream()
         if side is not None:
             # The block gradient (the blk x n row-oracle product: the largest kernel of the step)
@@ -234,7 +243,7 @@ class SAP(Solver):
                 if "grad" not in box:
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
-                        box["grad"] = self._block_gradient(loc, self.system.B[:, cols], blk_d)
+                        box["grad"] = self._block_gradient(loc, Bc, blk_d)
 
             early = os.environ.get("RK_SAP_GRAD_FIRST", "0") == "1"
             if early:
@@ -255,7 +264,7 @@ class SAP(Solver):
                 eta.record_stream(main)
         else:
             blk_precond, eta = self._precond_and_stepsize(blk)
-            grad = self._block_gradient(loc, self.system.B[:, cols], blk_d)
+            grad = self._block_gradient(loc, Bc, blk_d)
         d = blk_precond._inv @ grad
         if self._fused_update(cols, blk_d, d, eta):
             return
