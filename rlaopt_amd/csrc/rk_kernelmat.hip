@@ -685,7 +685,12 @@ static bool kmat_use_sym() {
 // (measured, n = 200 000, d = 64: k = 1 18.3 vs 26.1 ms, k = 2 20.0 vs 27.0, k = 4 24.5 vs 29.4; d = 32 does not
 // gain - the column sums are vector work and one k-step leaves little matrix-core time to save -, and below
 // n ~ 65 000 the work list and the finishing kernel cost more than the saved tiles)
-static int64_t sym_max_k() { const char* e = getenv("RK_KMAT_SYM_MAXK"); return e ? atoll(e) : 4; }
+// (the symmetric kernel has instantiations for k <= 4 only: the knob can lower the limit, not raise it)
+static int64_t sym_max_k() {
+    const char* e = getenv("RK_KMAT_SYM_MAXK");
+    const int64_t v = e ? atoll(e) : 4;
+    return v < 4 ? v : 4;
+}
 static int64_t sym_min_n() { const char* e = getenv("RK_KMAT_SYM_MINN"); return e ? atoll(e) : 65536; }
 
 static bool kmat_use_bf16x3() {

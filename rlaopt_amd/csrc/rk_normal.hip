@@ -80,12 +80,15 @@ normal_pass_kernel(const T* __restrict__ A, int64_t m, int64_t n, int64_t lda,
             int64_t i = i0 + r;
             if (i > m - 1) i = m - 1;  // clamp; masked below
             // (unconditional: a lane whose columns lie past n re-reads the first 16 bytes of its column
-            // chunk - every chunk starts inside the row - and is masked when the data is used; a
-            // conditional load makes the compiler drain the whole prefetch queue at the branch join,
-            // once per group of rows)
+            // chunk and is masked when the data is used; a chunk that starts at or past the end of the
+            // row - three steps of columns run the NS = 4 instantiation - falls back to chunk 0, so no
+            // load ever leaves the row; a conditional load makes the compiler drain the whole prefetch
+            // queue at the branch join, once per group of rows)
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-                a[r][s] = load_stream_at<V16>(A + i * lda + (int64_t)s * 64 * VW, col_ok[s] ? lane_off : 0u);
+            for (int s = 0; s < NS; ++s) {
+                const int64_t c0 = (int64_t)s * 64 * VW;
+                a[r][s] = load_stream_at<V16>(A + i * lda + (c0 < n ? c0 : 0), col_ok[s] ? lane_off : 0u);
+            }
         }
     };
     auto consume = [&](const V16 a[R][NS], T uo, int64_t i0) {

@@ -641,7 +641,8 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
             dev = self._shard_devices[self._rank]
             cfg = self._kernel_config_devices[dev]
             Ab = self._A1[blk.to(self._A1.device)].to(dev)
-            Kb = be.kernel_materialize(self._kind, Ab, Ab, cfg.lengthscale, scale=self._scaling)
+            A2b = Ab if _same_points(self._A1, self._A2) else self._A2[blk.to(self._A2.device)].to(dev)
+            Kb = be.kernel_materialize(self._kind, Ab, A2b, cfg.lengthscale, scale=self._scaling)
 
             def full_matvec(x, Kb=Kb):
                 return be.matmat(Kb, x)

@@ -236,9 +236,10 @@ class HipBackend:
                 nbytes = max(nbytes, self._lib.rk_kernel_matmat_sym_ws_bytes(_dt(X1), n1, kc))
             ws, wsn = self._workspace(dev, nbytes)
             es = V2.element_size()
-            img = self._x2_image(x2_cache, dev, kid, X1, X2, ld2, idx2, n1, n2, ell, ell_vec, gram_center, kc, same)
+            img = self._x2_image(x2_cache, dev, kid, X1, X2, ld2, idx2, n1, n2, ell, ell_vec, gram_center, kc, same,
+                                 lengthscale=lengthscale)
             if img is not None:
-                buf, ready = img
+                buf, ready, slot = img
                 valid = ctypes.c_int(0)
                 rc = self._lib.rk_kernel_matmat_cached(
                     _dt(X1), kid, _ptr(X1), n1, ld1, _ptr(idx1), _ptr(X2), n2, ld2, _ptr(idx2),
@@ -247,7 +248,7 @@ class HipBackend:
                     int(ready), ctypes.byref(valid), _stream(dev),
                 )
                 _lib.check(rc, "rk_kernel_matmat_cached")
-                x2_cache["ready"] = bool(valid.value)
+                slot["ready"] = bool(valid.value)
                 continue
             rc = self._lib.rk_kernel_matmat(
                 _dt(X1), kid, _ptr(X1), n1, ld1, _ptr(idx1), _ptr(X2), n2, ld2, _ptr(idx2),
@@ -257,27 +258,31 @@ class HipBackend:
             _lib.check(rc, "rk_kernel_matmat")
         return out[:, 0] if squeeze else out
 
-    def _x2_image(self, cache, dev, kid, X1, X2, ld2, idx2, n1, n2, ell, ell_vec, gram_center, kc, same):
-        """(buffer, ready) for ``rk_kernel_matmat_cached`` or None.  The cache is valid for exactly the
-        operands that wrote it and for the stream that did (later calls on that stream are ordered
-        behind the write; any other stream converts again)."""
+    def _x2_image(self, cache, dev, kid, X1, X2, ld2, idx2, n1, n2, ell, ell_vec, gram_center, kc, same,
+                  lengthscale=None):
+        """(buffer, ready, slot) for ``rk_kernel_matmat_cached`` or None.  One image per stream (a call on
+        another stream converts into its own buffer: nothing orders two streams' use of one).  An image
+        is valid for exactly the operands that wrote it: the key carries their addresses AND their
+        in-place modification counters, and the slot holds references to them, so that neither an
+        in-place update nor an address the allocator hands out again can make a stale image look
+        current."""
         if cache is None or gram_center is None or X1.dtype != torch.float32:
             return None
         nbytes = self._lib.rk_kernel_x2_image_bytes(_dt(X1), kid, n1, n2, X1.shape[1], kc, int(bool(same)))
         if nbytes == 0:
             return None
-        key = (X2.data_ptr(), n2, ld2, 0 if idx2 is None else idx2.data_ptr(), X1.shape[1], float(ell),
-               0 if ell_vec is None else ell_vec.data_ptr(), gram_center.data_ptr(), kid, dev.index,
-               _stream(dev))
-        buf = cache.get("buf")
+        ell_src = lengthscale if isinstance(lengthscale, torch.Tensor) else None
+        held = (X2, idx2, ell_src, gram_center)
+        key = (n2, ld2, X1.shape[1], float(ell), kid, dev.index) + tuple(
+            (0, 0) if t is None else (t.data_ptr(), t._version) for t in held)
+        slot = cache.setdefault("streams", {}).setdefault(_stream(dev), {})
+        buf = slot.get("buf")
         if buf is None or buf.numel() < nbytes or buf.device != dev:
             buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            cache.update(buf=buf, key=None, ready=False)
-        if cache.get("key") != key:
-            cache.update(key=key, ready=False)
-        # (the arguments above keep X2 / idx2 / the centre alive for the cache's lifetime only through the
-        # operator that owns both: a cache must not outlive its operator)
-        return buf, bool(cache.get("ready"))
+            slot.update(buf=buf, key=None, ready=False)
+        if slot.get("key") != key:
+            slot.update(key=key, ready=False, held=held)
+        return buf, bool(slot.get("ready")), slot
 
     # -- symmetric packed kernel matrices ------------------------------------------------------
     def sympack_materialize(self, kind, X, lengthscale, scale=1.0, first=0, stride=1, store_dtype=None):

@@ -182,8 +182,20 @@ class Nystrom(Preconditioner):
                 # back to the orthonormal sketch Q = Omega R^-1 (R^T R = Omega^T Omega) the spectral route
                 # assumes: Y, Core and the Gram block transform by R^-1
                 with small_host_lapack(self.config.rank):
-                    R = torch.linalg.cholesky(0.5 * (SO + SO.T), upper=True)
-                    Rinv = torch.linalg.solve_triangular(R, torch.eye(R.shape[0], dtype=torch.float64), upper=True)
+                    SOs = 0.5 * (SO + SO.T)
+                    R, info = torch.linalg.cholesky_ex(SOs, upper=True)
+                    if int(info) == 0:
+                        Rinv = torch.linalg.solve_triangular(R, torch.eye(R.shape[0], dtype=torch.float64), upper=True)
+                    else:
+                        # Omega^T Omega is not numerically positive definite (a rank-deficient raw draw):
+                        # orthonormalise the directions that carry weight, Omega W with W = V diag(lam^-1/2)
+                        # (zero columns for the others: they contribute sigma = 0, which the spectral route
+                        # clips exactly as the reference clips its own)
+                        lam, Vs = torch.linalg.eigh(SOs)
+                        keep = lam > lam[-1] * SOs.shape[0] * torch.finfo(torch.float64).eps
+                        if not bool(torch.isfinite(lam).all()) or not bool(keep.any()):
+                            raise RuntimeError("Nystrom: the sketch image is not finite / has no range")
+                        Rinv = Vs * torch.where(keep, lam.clamp_min(1e-300).rsqrt(), torch.zeros_like(lam))
                     core = Rinv.T @ core @ Rinv
                     gram = Rinv.T @ gram @ Rinv
                 Y = get_backend().gemm(Y, Rinv.to(device=device, dtype=A.dtype))

@@ -10,6 +10,7 @@ import torch
 
 from conftest import DTYPES, TOL, load_golden
 from oracle import kernels as ok
+from oracle import nystrom as on
 from rlaopt_amd import sketches
 from rlaopt_amd.kernels import KernelConfig, RBFLinOp
 from rlaopt_amd.linops import LinOp, SymmetricLinOp
@@ -191,6 +192,39 @@ def test_nystrom_block_update_skips_the_qr_of_an_ortho_sketch_exactly(dev, prec,
         if deficient and dt == torch.float32:
             continue  # (rounding noise / shift is O(1) here: the clipped directions are noise in either route)
         assert float((a - b).abs().max() / b.abs().max()) < tol
+
+
+def test_nystrom_block_update_survives_a_rank_deficient_raw_draw(dev, prec, monkeypatch):
+    """A raw (un-orthonormalised) Ortho draw whose columns are linearly dependent: Omega^T Omega has no
+    Cholesky factor, the Cholesky-only route declines, and the fallback must reach the spectral route
+    (orthonormalising the directions that carry weight) instead of raising on the same matrix."""
+    from rlaopt_amd import sketches as sk
+
+    dt = DTYPES[prec]
+    gen = torch.Generator().manual_seed(21)
+    n, rank = 96, 12
+    Q, _ = torch.linalg.qr(torch.randn(n, n, dtype=torch.float64, generator=gen))
+    A = (Q * torch.arange(1, n + 1, dtype=torch.float64) ** -2.0) @ Q.T
+    A = (0.5 * (A + A.T)).to(dt).to(dev)
+    draw = torch.randn(n, rank, dtype=torch.float64, generator=gen)
+    draw[:, rank - 1] = draw[:, 0]          # an exact repeat ...
+    draw[:, rank - 2] = draw[:, 1] * 2.0    # ... and a multiple: rank(Omega) = rank - 2
+    monkeypatch.setattr(sk, "_device_randn", lambda rows, cols, dtype, device: draw.to(device=device, dtype=dtype))
+    P = Nystrom(NystromConfig(rank=rank, rho=1e-3, sketch="ortho", damping_mode="non_adaptive"))
+    P._update_block(A, dev, 1e-3)
+    assert not P._raw and P.S is not None and P.S.shape == (rank,)
+    S = P.S.cpu().double()
+    assert int((S > 1e-6 * S.max()).sum()) <= rank - 2  # the dependent directions carry no spectrum
+    # and what is left is the Nystrom approximation on range(Omega): compare with the oracle's on an
+    # orthonormal basis of the independent columns
+    x = torch.randn(n, dtype=dt, generator=gen).to(dev)
+    got = (P._inv @ x).cpu().double()
+    assert bool(torch.isfinite(got).all())
+    Qi, _ = torch.linalg.qr(draw[:, : rank - 2])
+    st = on.build(A.cpu().double(), Qi, 1e-3)
+    want = on.inverse_matmul(st, x.cpu().double()[:, None])[:, 0]
+    tol = 1e-6 if dt == torch.float64 else 5e-2
+    assert float((got - want).norm() / want.norm()) < tol
 
 
 def test_nystrom_instances_sharing_a_config_keep_their_own_damping(dev, prec):

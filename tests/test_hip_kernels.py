@@ -281,7 +281,10 @@ def test_gram_small_block_inner_products(be, prec, n, k1, k2):
 
 
 @pytest.mark.parametrize("m,n,k,lda_pad", [(3, 8, 1, 0), (1000, 512, 1, 0), (4099, 128, 2, 0), (777, 100, 1, 4),
-                                           (5000, 256, 2, 8), (260, 2, 1, 0), (9000, 384, 1, 0)])
+                                           (5000, 256, 2, 8), (260, 2, 1, 0), (9000, 384, 1, 0),
+                                           # three 16-byte steps per lane run the four-step instantiation: its
+                                           # last column chunk starts at the end of the row (lda == n)
+                                           (777, 768, 1, 0), (2051, 768, 2, 0), (1029, 640, 1, 0), (515, 320, 2, 0)])
 def test_normal_pass_one_sweep(be, prec, m, n, k, lda_pad):
     """rk_normal_pass: U <- A Z - U diag(coef), G = A^T U_new, ss = |U_new|^2 from one pass."""
     dt = DTYPES[prec]
@@ -749,6 +752,11 @@ def test_kernel_matmat_keeps_the_x2_image_between_calls(be, monkeypatch, kind, d
     gc = be.gram_center(X, X, 1.0)
     assert gc is not None
     cache = {}
+
+    def slot(c, stream=None):
+        stream = torch.cuda.current_stream() if stream is None else stream
+        return c.get("streams", {}).get(stream.cuda_stream, {})
+
     for step in range(3):
         blk = torch.randperm(n2, generator=g)[:200].to(dev())
         V = torch.randn(n2, k, generator=g).to(dev())
@@ -756,31 +764,40 @@ def test_kernel_matmat_keeps_the_x2_image_between_calls(be, monkeypatch, kind, d
         plain = be.kernel_matmat(kind, A1, X, 1.0, V, gram_center=gc)
         kept = be.kernel_matmat(kind, A1, X, 1.0, V, gram_center=gc, x2_cache=cache)
         assert torch.equal(plain, kept)
-        assert cache["ready"] is True and cache["buf"].numel() > 0
+        assert slot(cache)["ready"] is True and slot(cache)["buf"].numel() > 0
         if step == 1:
-            buf_ptr = cache["buf"].data_ptr()
-    assert cache["buf"].data_ptr() == buf_ptr  # (one buffer for the lifetime of the cache)
+            buf_ptr = slot(cache)["buf"].data_ptr()
+    assert slot(cache)["buf"].data_ptr() == buf_ptr  # (one buffer per stream for the lifetime of the cache)
+    # the points change IN PLACE (same address): the image is converted again
+    Xm = X.clone()
+    cm = {}
+    V = torch.randn(n2, k, generator=g).to(dev())
+    be.kernel_matmat(kind, X[:100].contiguous(), Xm, 1.0, V, gram_center=gc, x2_cache=cm)
+    assert slot(cm)["ready"] is True
+    Xm.mul_(0.75)
+    got = be.kernel_matmat(kind, X[:100].contiguous(), Xm, 1.0, V, gram_center=gc, x2_cache=cm)
+    assert torch.equal(got, be.kernel_matmat(kind, X[:100].contiguous(), Xm, 1.0, V, gram_center=gc))
     # other operands: converted again, correct again
     X2 = (X * 0.5).contiguous()
-    V = torch.randn(n2, k, generator=g).to(dev())
     got = be.kernel_matmat(kind, X[:100].contiguous(), X2, 1.0, V, gram_center=gc, x2_cache=cache)
     assert torch.equal(got, be.kernel_matmat(kind, X[:100].contiguous(), X2, 1.0, V, gram_center=gc))
-    # another stream: not ordered behind the write - converted again
+    # another stream: not ordered behind the write - it converts into a buffer of its own
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         got2 = be.kernel_matmat(kind, X[:100].contiguous(), X2, 1.0, V, gram_center=gc, x2_cache=cache)
     side.synchronize()
     assert torch.equal(got2, got)
+    assert slot(cache, side)["buf"].data_ptr() != slot(cache)["buf"].data_ptr()
     # a formulation without images: nothing is kept
     monkeypatch.setenv("RK_KMAT_BF16X3", "0")
     c2 = {}
     be.kernel_matmat(kind, X[:100].contiguous(), X2, 1.0, V, gram_center=gc, x2_cache=c2)
-    assert c2.get("ready") is False
+    assert slot(c2).get("ready") is False
     monkeypatch.delenv("RK_KMAT_BF16X3")
     got3 = be.kernel_matmat(kind, X[:100].contiguous(), X2, 1.0, V, gram_center=gc, x2_cache=c2)
-    assert c2["ready"] is True and torch.equal(got3, got)
+    assert slot(c2)["ready"] is True and torch.equal(got3, got)
     # symmetric operands and float64 keep no image
     c3 = {}
     be.kernel_matmat(kind, X, X, 1.0, V[:, :2].contiguous(), gram_center=gc, x2_cache=c3)
-    assert "buf" not in c3
+    assert "streams" not in c3
