@@ -55,37 +55,117 @@ def make_problem(n, d, r, dt, seed_x=0, seed_om=1):
     return X, B, Om
 
 
-def cpu_baseline(X, n, budget_s=12.0):
-    """CPU leg: the oracle's C/OpenMP matrix-free RBF product on a growing row sample of the
-    SAME n x n system until ~budget_s of host work has been measured; converted to PCG
-    iterations/s (the kernel product is > 99 % of a CPU iteration: SURVEY 8a, row a11)."""
-    from oracle import cbind
+def es_of(dt):
+    return 4 if dt == torch.float32 else 8
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def cpu_baseline(X, n, d, r, callback_freq, dev, budget_s=30.0):
+    """CPU leg, two parts, both on the oracle's C/OpenMP matrix-free RBF product (the reference's CPU
+    path is pykeops' matrix-free CPU backend):
+
+    1. ``value``: the product timed on a growing row sample of the SAME n x n system, converted to PCG
+       iterations/s of that system (the product is > 99 % of a CPU iteration: SURVEY 8a, row a11) -
+       an extrapolation, labelled as such;
+    2. ``solve``: an ACTUAL solve - Nystrom assembly + block PCG + LinSys loop of the oracle
+       (oracle/krr.py), same recipe (seeds, rank, reg = 1e-6 n, rtol = 1e-6, callback_freq), same dtype,
+       at the largest n of the ladder whose estimated cost fits ``budget_s`` of host work - with its
+       iterations, final relative residual and wall time; ``gpu_same_system`` is the product's solve of
+       that very system (same Omega) on the GPU, timed the same way."""
+    from oracle import cbind, krr
 
     cores = cbind.num_threads()
-    V = torch.ones(n, 1, dtype=X.dtype)
-    rows, spent, done_rows = 256, 0.0, 0
+    dt = X.dtype
+    V = torch.ones(n, 1, dtype=dt)
+    rows, spent = 256, 0.0
     cbind.kernel_matmat("rbf", X[:64], X, 1.0, V)  # warm the threads
-    while spent < budget_s and rows <= n:
+    while spent < 4.0 and rows <= n:
         t = time.time()
         cbind.kernel_matmat("rbf", X[:rows], X, 1.0, V)
-        dt = time.time() - t
-        spent += dt
-        done_rows += rows
-        last = (rows, dt)
+        el = time.time() - t
+        spent += el
+        last = (rows, el)
         rows *= 2
     pair_rate = last[0] * n / last[1]
     sec_per_iter = n * n / pair_rate * 1.1  # + the residual product every 10th iteration
-    return {
+    out = {
         "value": 1.0 / sec_per_iter,
         "unit": "iter/s",
         "cores": cores,
+        "cpu_model": _cpu_model(),
         "kind": "port",
-        "sample": f"oracle/rk_oracle.c matrix-free RBF product, rows 0..{last[0]} of the n={n} d={X.shape[1]} "
-                  f"system in {last[1]:.2f}s ({pair_rate / 1e9:.3f} Gpair/s on {cores} threads), "
-                  f"extrapolated to one full product x 1.1; {spent:.1f}s of host work in all "
-                  f"(doubling row samples up to that one)",
+        "sample": f"EXTRAPOLATED: oracle/rk_oracle.c matrix-free RBF product, rows 0..{last[0]} of the n={n} "
+                  f"d={d} system in {last[1]:.2f}s ({pair_rate / 1e9:.3f} Gpair/s on {cores} threads) -> one "
+                  f"full product x 1.1 per iteration; the measured solve is under 'solve'",
         "gpair_per_s": pair_rate / 1e9,
     }
+    # ---- the measured solve ---------------------------------------------------------------------------------
+    # The float32 kernel matrix is written once by the C closed forms and every product is an MKL sgemv / sgemm
+    # over it: the FASTER of the two host paths (the matrix-free product the reference's pykeops CPU backend takes
+    # would spend n^2 (d + 24) flops per iteration instead of streaming n^2 words).  A first rung (n = 6 000) is
+    # timed; the solve reported is the largest rung of the ladder whose cost, scaled by n^2 from the first, fits
+    # the budget (n = 50 000 is BASELINE.json's configs[1]).
+    max_iters = 200
+
+    def host_solve(nc):
+        r_c = min(r, nc // 40)
+        Xc, Bc, Omc = make_problem(nc, d, r_c, dt)
+        t0 = time.time()
+        ref = krr.solve(Xc, Bc, Omc, 1e-6 * nc, rtol=1e-6, atol=0.0, max_iters=max_iters,
+                        callback_freq=callback_freq, dense=True)
+        return nc, r_c, Xc, Bc, Omc, ref, time.time() - t0
+
+    run = host_solve(min(6000, n))
+    for cand in (50000, 30000, 20000, 12000):
+        if cand <= n and cand * cand * es_of(dt) <= 16e9 and run[-1] * (cand / run[0]) ** 2 <= budget_s:
+            run = host_solve(cand)
+            break
+    n_cpu, r_c, Xc, Bc, Omc, ref, wall = run
+    reg = 1e-6 * n_cpu
+    out["solve"] = {
+        "workload": f"rbf_krr_pcg n={n_cpu} d={d} k=1 nystrom_rank={r_c} reg=1e-6*n rtol=1e-6 {str(dt)[6:]}",
+        "host_path": "dense K written once (oracle/rk_oracle.c closed forms, OpenMP) + MKL sgemv/sgemm + "
+                     "oracle Nystrom / block PCG / LinSys loop (oracle/krr.py)",
+        "iters": int(ref["iters"]), "rel_res": float(ref["rel_res"][0]), "wall_s": round(wall, 3),
+        "nystrom_build_s": round(ref["build_s"], 3), "loop_s": round(ref["loop_s"], 3),
+        "iters_per_s": ref["iters"] / ref["loop_s"], "products": ref["products"], "cores": cores,
+    }
+    # the same system through the product, same Omega
+    from rlaopt_amd import sketches
+    from rlaopt_amd.kernels import KernelConfig, RBFLinOp
+    from rlaopt_amd.models import LinSys
+    from rlaopt_amd.preconditioners import NystromConfig
+    from rlaopt_amd.solvers import PCGConfig
+
+    Xg = Xc.to(dev)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    A = RBFLinOp(Xg, Xg, KernelConfig(lengthscale=1.0))
+    cfg = PCGConfig(device=dev, max_iters=max_iters, atol=0.0, rtol=1e-6,
+                    precond_config=NystromConfig(rank=r_c, rho=reg, sketch="gauss"))
+    with sketches.inject(Omc.to(dev)):
+        Wg, log = LinSys(A, Bc.to(dev), reg=reg).solve(cfg, torch.zeros(n_cpu, 1, dtype=dt, device=dev),
+                                                       callback_freq=callback_freq)
+    torch.cuda.synchronize()
+    gwall = time.time() - t0
+    last_it = max(log)
+    out["gpu_same_system"] = {
+        "iters": int(last_it), "rel_res": float(log[last_it]["metrics"]["internal_metrics"]["rel_res"][0]),
+        "wall_s": round(gwall, 3), "storage": A.storage_mode,
+        "speedup_wall": wall / gwall,
+        "first_logged_rel_res": [float(log[i]["metrics"]["internal_metrics"]["rel_res"][0]) for i in sorted(log)[:4]],
+        "cpu_first_logged_rel_res": [float(ref["log"][i]["rel_res"][0]) for i in sorted(ref["log"])[:4]],
+    }
+    return out
 
 
 def committed_traffic(world, n, mode):
@@ -197,7 +277,10 @@ def main():
     def one_iteration(i):
         solver._step()
         if i % args.callback_freq == 0:
-            system._compute_internal_metrics(solver.W)
+            # what a logged iteration of LinSys.solve does: the metric and the termination test with
+            # its one host read (rtol = 0: never satisfied, the loop keeps its k = 1 active column)
+            m = system._compute_internal_metrics(solver.W)
+            system._check_termination_criteria(m, 0.0, 0.0)
 
     # ---- warmup, then exactly K timed steps ---------------------------------------------------
     # the warmup must touch every code path of a step, including the logging-iteration metrics
@@ -300,6 +383,51 @@ def main():
         }
         del Omd
 
+    # ---- the converging configuration of the same system: float64 iteration over float32 storage ---------
+    # (the float32 solve above stalls at eps32 x condition number and runs to max_iters; with the packed
+    # triangle still in float32 - same HBM traffic - and every vector and accumulation in float64 it meets
+    # rtol = 1e-6.  Same X (the float32 values), same B, same Omega.)
+    converging = None
+    if not args.no_solve and args.dtype == "f32" and mode.startswith("sympack"):
+        del solver, system
+        if "system2" in dir():
+            del system2
+        A.shutdown()
+        del A
+        torch.cuda.empty_cache()
+        os.environ["RK_STORAGE_DTYPE"] = "float32"
+        try:
+            sync()
+            t0 = time.time()
+            X64 = Xd.double()
+            A64 = DistributedRBFLinOp(X64, X64, KernelConfig(lengthscale=1.0), devices={dev})
+            sys64 = LinSys(A64, Bd.double(), reg=reg)
+            cfg = PCGConfig(device=dev, max_iters=200, atol=0.0, rtol=1e-6,
+                            precond_config=NystromConfig(rank=r, rho=reg, sketch="gauss"))
+            Om64 = Om.to(dev).double()
+            with sketches.inject(Om64):
+                W64, log64 = sys64.solve(cfg, torch.zeros(n, k, dtype=torch.float64, device=dev),
+                                         callback_freq=args.callback_freq)
+            sync()
+            t_all = time.time() - t0
+            last = max(log64)
+            # iterations/s of the loop alone: re-time a few steps on the converged state's solver
+            converging = {
+                "config": "float64 vectors / accumulation, packed triangle stored in float32 (RK_STORAGE_DTYPE=float32)",
+                "iters": int(last),
+                "rel_res": float(log64[last]["metrics"]["internal_metrics"]["rel_res"][0]),
+                "history": [float(log64[i]["metrics"]["internal_metrics"]["rel_res"][0]) for i in sorted(log64)],
+                "wall_s_with_setup": round(t_all, 3),
+                "loop_s": round(log64[last]["cum_time"], 3) if "cum_time" in log64[last] else None,
+                "storage": A64.storage_mode,
+            }
+            del Om64, W64, sys64
+            A64.shutdown()
+            del A64, X64
+            torch.cuda.empty_cache()
+        finally:
+            del os.environ["RK_STORAGE_DTYPE"]
+
     if rank == 0:
         out = {
             "metric": "pcg_iters_per_sec",
@@ -348,9 +476,10 @@ def main():
             "rel_res_after_timed_steps": rel_now,
             "launch_timing": {op: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 4)} for op, v in timing.items()},
             **solve,
+            "converging_solve": converging,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(X, n)  # same dtype as the GPU run
+            out["cpu_baseline"] = cpu_baseline(X, n, d, r, args.callback_freq, dev)  # same dtype as the GPU run
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -22,6 +22,12 @@ def load():
             fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                            ctypes.c_int64, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p,
                            ctypes.c_double, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+        for name in ("rk_oracle_kernel_matrix_f32", "rk_oracle_kernel_matrix_f64"):
+            fn = getattr(_lib, name)
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                           ctypes.c_int64, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p,
+                           ctypes.c_double, ctypes.c_void_p]
         _lib.rk_oracle_num_threads.restype = ctypes.c_int
     return _lib
 
@@ -48,3 +54,21 @@ def kernel_matmat(kind, X1, X2, lengthscale, V, const_scaling=1.0):
     if rc != 0:
         raise ValueError("rk_oracle_kernel_matmat: bad arguments")
     return Y[:, 0] if V.ndim == 1 else Y
+
+
+def kernel_matrix(kind, X1, X2, lengthscale, const_scaling=1.0):
+    """Dense const_scaling * K(X1, X2) on the host cores (OpenMP), float32 or float64."""
+    lib = load()
+    X1, X2 = X1.contiguous(), X2.contiguous()
+    ell_vec, ell = None, 1.0
+    if isinstance(lengthscale, torch.Tensor):
+        ell_vec = lengthscale.to(X1.dtype).contiguous()
+    else:
+        ell = float(lengthscale)
+    K = torch.empty((X1.shape[0], X2.shape[0]), dtype=X1.dtype)
+    fn = lib.rk_oracle_kernel_matrix_f32 if X1.dtype == torch.float32 else lib.rk_oracle_kernel_matrix_f64
+    rc = fn(_KINDS[kind], X1.data_ptr(), X1.shape[0], X2.data_ptr(), X2.shape[0], X1.shape[1], ell,
+            None if ell_vec is None else ell_vec.data_ptr(), float(const_scaling), K.data_ptr())
+    if rc != 0:
+        raise ValueError("rk_oracle_kernel_matrix: bad arguments")
+    return K

@@ -63,6 +63,51 @@
         return 0;                                                                               \
     }
 
+/* The same entries written out: K (n1 x n2, row-major) = scale * K(X1, X2).  Used by the parity tests that
+ * need the dense operator of a mid-size system on the host (the reference's composite oracle: a dense torch
+ * K behind its own LinOp). */
+#define DEFINE_ORACLE_MATRIX(NAME, T, EXP, SQRT, FABS)                                           \
+    int NAME(int kind, const T* X1, int64_t n1, const T* X2, int64_t n2, int64_t d, double ell,  \
+             const T* ell_vec, double scale, T* K) {                                             \
+        if (kind < 0 || kind > 4 || n1 <= 0 || n2 <= 0 || d <= 0) return -1;                    \
+        const T s3 = (T)1.7320508075688772, s5 = (T)2.23606797749979;                           \
+        _Pragma("omp parallel") {                                                                \
+            T* w = (T*)malloc((size_t)d * sizeof(T));                                           \
+            for (int64_t c = 0; c < d; ++c) w[c] = (T)1 / (ell_vec ? ell_vec[c] : (T)ell);      \
+            _Pragma("omp for schedule(dynamic, 8)") for (int64_t i = 0; i < n1; ++i) {          \
+                const T* xi = X1 + i * d;                                                       \
+                for (int64_t j = 0; j < n2; ++j) {                                              \
+                    const T* y = X2 + j * d;                                                    \
+                    T s = 0;                                                                    \
+                    if (kind == 1) {                                                            \
+                        _Pragma("omp simd reduction(+ : s)")                                    \
+                        for (int64_t c = 0; c < d; ++c) s += FABS((xi[c] - y[c]) * w[c]);       \
+                    } else {                                                                    \
+                        _Pragma("omp simd reduction(+ : s)")                                    \
+                        for (int64_t c = 0; c < d; ++c) {                                       \
+                            const T df = (xi[c] - y[c]) * w[c];                                 \
+                            s += df * df;                                                       \
+                        }                                                                       \
+                    }                                                                           \
+                    T kv;                                                                       \
+                    if (kind == 0) kv = EXP(-s / 2);                                            \
+                    else if (kind == 1) kv = EXP(-s);                                           \
+                    else {                                                                      \
+                        const T D = SQRT(s);                                                    \
+                        if (kind == 2) kv = EXP(-D);                                            \
+                        else if (kind == 3) kv = ((T)1 + s3 * D) * EXP(-s3 * D);                \
+                        else kv = ((T)1 + s5 * D + (T)(5.0 / 3.0) * D * D) * EXP(-s5 * D);      \
+                    }                                                                           \
+                    K[i * n2 + j] = (T)scale * kv;                                              \
+                }                                                                               \
+            }                                                                                   \
+            free(w);                                                                            \
+        }                                                                                       \
+        return 0;                                                                               \
+    }
+
+DEFINE_ORACLE_MATRIX(rk_oracle_kernel_matrix_f32, float, expf, sqrtf, fabsf)
+DEFINE_ORACLE_MATRIX(rk_oracle_kernel_matrix_f64, double, exp, sqrt, fabs)
 DEFINE_ORACLE(rk_oracle_kernel_matmat_f32, float, expf, sqrtf, fabsf)
 DEFINE_ORACLE(rk_oracle_kernel_matmat_f64, double, exp, sqrt, fabs)
 

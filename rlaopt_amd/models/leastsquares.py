@@ -15,6 +15,7 @@ from ..linops import _is_linop_or_torch_tensor
 from ..ops import get_backend
 from ..solvers import _get_solver, _get_solver_name, _is_solver_config
 from ..utils import Logger, _is_nonneg_float, _is_torch_tensor
+from .linsys import _device_sync
 from .model import Model
 
 __all__ = ["LeastSquares"]
@@ -115,6 +116,7 @@ class LeastSquares(Model):
                 solver_name=_get_solver_name(solver_config), solver_config=solver_config,
                 callback_freq=callback_freq,
             ),
+            sync=_device_sync(self._B),
         )
         solver = _get_solver(model=self, W_init=W_init, solver_config=solver_config)
         return self._train(

@@ -94,6 +94,14 @@ class _ExecContext:
         return self.gram(X, X).diagonal().clamp_min(0.0).sqrt()
 
 
+def _device_sync(t: torch.Tensor):
+    """What the logger calls before reading the clock (utils/logger.py)."""
+    if not t.is_cuda:
+        return None
+    dev = t.device
+    return lambda: torch.cuda.synchronize(dev)
+
+
 class LinSys(Model):
     """Positive-definite linear system (A + reg * I) W = B."""
 
@@ -170,6 +178,7 @@ class LinSys(Model):
                 solver_name=_get_solver_name(solver_config), solver_config=solver_config,
                 callback_freq=callback_freq,
             ),
+            sync=_device_sync(self._B),
         )
         solver = _get_solver(model=self, W_init=W_init, solver_config=solver_config)
         self._active_solver = solver

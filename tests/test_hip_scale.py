@@ -290,3 +290,104 @@ def test_askotch_size_row_oracle_against_c_oracle(be):
     assert float((got[pick.to(DEV)].cpu() - want).norm() / want.norm()) < 2e-5
     pre = be.kernel_matmat("rbf", Xd[bd], Xd, 1.0, Vd)
     assert float((got - pre).norm() / pre.norm()) < 1e-6
+
+
+# ---- the benchmark's own numerical regime: float32, reg = 1e-6 n, rtol = 1e-6 (BASELINE configs 2 / 3) ----
+BENCH_REGIME = {}
+
+
+def _bench_regime_problem():
+    """n = 20 000, d = 64, Nystrom rank 256, the recipe of SURVEY 8(d) / bench.py: X = randn / sqrt(d),
+    B = randn, Omega = randn(r, n) / sqrt(r) transposed, float64 draws cast to float32.  The host side is
+    the composite oracle (oracle/krr.py): the dense float32 kernel matrix from the C closed forms behind
+    the restated Nystrom (float32 branch, nystrom.py:118-127) + block PCG + LinSys loop."""
+    if BENCH_REGIME:
+        return BENCH_REGIME
+    from oracle import krr
+
+    n, d, r = 20000, 64, 256
+    dt = torch.float32
+    g = torch.Generator().manual_seed(0)
+    X = (torch.randn(n, d, dtype=torch.float64, generator=g) / d**0.5).to(dt)
+    B = torch.randn(n, 1, dtype=torch.float64, generator=g).to(dt)
+    g = torch.Generator().manual_seed(1)
+    Om = (torch.randn(r, n, dtype=torch.float64, generator=g) / r**0.5).T.contiguous().to(dt)
+    reg = 1e-6 * n
+    ref = krr.solve(X, B, Om, reg, rtol=1e-6, atol=0.0, max_iters=200, callback_freq=10, dense=True)
+    # the same solve with float64 arithmetic on the SAME float32 data: what the float32 runs stall against
+    ref64 = krr.solve(X.double(), B.double(), Om.double(), reg, rtol=1e-6, atol=0.0, max_iters=200,
+                      callback_freq=10, dense=True)
+    BENCH_REGIME.update(n=n, d=d, r=r, X=X, B=B, Om=Om, reg=reg, ref=ref, ref64=ref64)
+    return BENCH_REGIME
+
+
+def _history(log):
+    its = sorted(log)
+    return its, torch.tensor([float(log[i]["rel_res"][0]) if "rel_res" in log[i]
+                              else float(log[i]["metrics"]["internal_metrics"]["rel_res"][0]) for i in its])
+
+
+@pytest.mark.parametrize("mode", ["sympack", "materialize", "matrix_free"])
+def test_benchmark_regime_float32_solve_matches_oracle(mode, monkeypatch):
+    """The headline's regime is one where float32 block PCG does NOT reach rtol = 1e-6: it runs to
+    max_iters and stalls at eps32 x condition number.  Pinned here, per storage mode, against the oracle
+    with the same injected Omega: same logged iterations (all 200), the first three logged residuals
+    within 3e-2 (reference fp32 tolerance for a PCG history, see check_pcg_parity), the descent phase
+    (residuals above 10 x the stall level) inside a factor 1.5, and the stall level - the median of the last
+    five logged residuals - at most 2 x the oracle's (lower is better and is accepted).  Two float32
+    evaluations of the same operator (dense sgemv against the matrix-free C product) already differ by
+    1.4 x in where they stall (n = 3 000 probe), hence the factor."""
+    p = _bench_regime_problem()
+    n, r, reg = p["n"], p["r"], p["reg"]
+    monkeypatch.setenv("RK_KERNEL_MODE", mode)
+    Xd = p["X"].to(DEV)
+    A = RBFLinOp(Xd, Xd, KernelConfig(lengthscale=1.0))
+    assert A.storage_mode.startswith(mode)
+    cfg = PCGConfig(device=DEV, max_iters=200, atol=0.0, rtol=1e-6,
+                    precond_config=NystromConfig(rank=r, rho=reg, sketch="gauss"))
+    system = LinSys(A, p["B"].to(DEV), reg=reg)
+    with sketches.inject(p["Om"]):
+        W, log = system.solve(cfg, torch.zeros(n, 1, dtype=torch.float32, device=DEV), callback_freq=10)
+    its, rel = _history(log)
+    ref_its, want = _history(p["ref"]["log"])
+    _, want64 = _history(p["ref64"]["log"])
+    stall, ref_stall = float(rel[-5:].median()), float(want[-5:].median())
+    print(f"\n[bench regime n={n} r={r} {mode}] iters {its[-1]} (oracle {ref_its[-1]}, float64 oracle "
+          f"{sorted(p['ref64']['log'])[-1]}), stall {stall:.3e} (oracle {ref_stall:.3e}, float64 oracle final "
+          f"{float(want64[-1]):.3e}), rho {cfg.precond_config.rho:.6e} (oracle {p['ref']['rho']:.6e})")
+    assert its == ref_its, (its[-1], ref_its[-1])
+    assert abs(cfg.precond_config.rho - p["ref"]["rho"]) <= 1e-3 * p["ref"]["rho"]
+    torch.testing.assert_close(rel[:3], want[:3], rtol=3e-2, atol=0)
+    descent = want > 10 * ref_stall
+    ratio = rel[descent] / want[descent]
+    assert float(ratio.max()) < 1.5 and float(ratio.min()) > 1 / 1.5, ratio
+    assert stall <= 2.0 * ref_stall, (stall, ref_stall)
+    # the solution itself: distance to the oracle's in residual space is at the stall level
+    D = (W.cpu() - p["ref"]["W"]).double()
+    Kd = cbind.kernel_matmat("rbf", p["X"].double(), p["X"].double(), 1.0, D)
+    gap = float(torch.linalg.norm(Kd + reg * D) / torch.linalg.norm(p["B"].double()))
+    assert gap <= 4.0 * max(stall, ref_stall), (gap, stall, ref_stall)
+
+
+def test_benchmark_regime_float64_iteration_on_float32_storage_converges(monkeypatch):
+    """The converging configuration of the same system: float64 vectors and accumulation over a packed
+    triangle stored in float32 (RK_STORAGE_DTYPE).  Against the float64 oracle on the float32-rounded
+    operator: same iteration count, history to 1e-3 (the stored entries differ from the oracle's float32
+    entries by their last bit: both are float32 roundings of the same closed form)."""
+    p = _bench_regime_problem()
+    n, r, reg = p["n"], p["r"], p["reg"]
+    monkeypatch.setenv("RK_KERNEL_MODE", "sympack")
+    monkeypatch.setenv("RK_STORAGE_DTYPE", "float32")
+    Xd = p["X"].double().to(DEV)
+    A = RBFLinOp(Xd, Xd, KernelConfig(lengthscale=1.0))
+    cfg = PCGConfig(device=DEV, max_iters=200, atol=0.0, rtol=1e-6,
+                    precond_config=NystromConfig(rank=r, rho=reg, sketch="gauss"))
+    system = LinSys(A, p["B"].double().to(DEV), reg=reg)
+    with sketches.inject(p["Om"].double()):
+        W, log = system.solve(cfg, torch.zeros(n, 1, dtype=torch.float64, device=DEV), callback_freq=10)
+    its, rel = _history(log)
+    ref_its, want = _history(p["ref64"]["log"])
+    print(f"\n[bench regime float64 iteration / float32 storage] iters {its[-1]} (oracle {ref_its[-1]}), "
+          f"final {float(rel[-1]):.3e} (oracle {float(want[-1]):.3e})")
+    assert its == ref_its and float(rel[-1]) <= 1e-6
+    torch.testing.assert_close(rel[:-1], want[:-1].to(rel.dtype), rtol=2e-2, atol=0)

@@ -181,3 +181,56 @@ def test_sap_trajectory_matches_reference(prec, pname, accel):
         torch.testing.assert_close(rel, g[f"{key}_rel_res"], **tol)
     finally:
         torch.set_default_dtype(old)
+
+
+# ---- the C restatement (oracle/rk_oracle.c): the checker of every full-size GPU assertion and the CPU baseline ----
+@pytest.mark.parametrize("kind", ok.KINDS)
+@pytest.mark.parametrize("shape", ["small", "ragged"])
+@pytest.mark.parametrize("ell", ["scalar", "ard"])
+def test_c_oracle_entries_match_reference_closed_form(prec, kind, shape, ell):
+    """``cbind.kernel_matmat`` with V = I returns the kernel matrix itself: every entry against the
+    golden matrices generated by the reference test-suite's closed forms (tests/kernels/utils.py:4-60),
+    5 kinds x scalar / per-feature lengthscale x float32 / float64, reference tolerances."""
+    from oracle import cbind
+
+    g = load_golden(f"kernels_{prec}")
+    X1, X2 = g[f"{shape}_X1"], g[f"{shape}_X2"]
+    lengthscale = 1.0 if ell == "scalar" else g[f"{shape}_ard"]
+    eye = torch.eye(X2.shape[0], dtype=DTYPES[prec])
+    K = cbind.kernel_matmat(kind, X1, X2, lengthscale, eye, 2.0)
+    torch.testing.assert_close(K, g[f"{shape}_{kind}_{ell}"], **TOL[DTYPES[prec]])
+    torch.testing.assert_close(cbind.kernel_matrix(kind, X1, X2, lengthscale, 2.0), g[f"{shape}_{kind}_{ell}"],
+                               **TOL[DTYPES[prec]])
+
+
+@pytest.mark.parametrize("kind", ok.KINDS)
+def test_c_oracle_products_match_python_oracle(prec, kind):
+    """Products (vector and block right-hand sides, ragged shapes that do not divide the OpenMP chunking)
+    against the golden dense K and against ``oracle/kernels.py`` on a larger seeded problem."""
+    from oracle import cbind
+
+    g = load_golden(f"kernels_{prec}")
+    dt = DTYPES[prec]
+    tol = TOL[dt]
+    X1, X2, ard = g["ragged_X1"], g["ragged_X2"], g["ragged_ard"]
+    K = g[f"ragged_{kind}_ard"]
+    gen = torch.Generator().manual_seed(3)
+    v = torch.randn(X2.shape[0], dtype=dt, generator=gen)
+    M = torch.randn(X2.shape[0], 3, dtype=dt, generator=gen)
+    got = cbind.kernel_matmat(kind, X1, X2, ard, v, 2.0)
+    assert got.shape == (X1.shape[0],)
+    torch.testing.assert_close(got, K @ v, **tol)
+    torch.testing.assert_close(cbind.kernel_matmat(kind, X1, X2, ard, M, 2.0), K @ M, **tol)
+    n1, n2, d, k = 301, 1013, 19, 5
+    A1 = torch.randn(n1, d, dtype=dt, generator=gen) / d**0.5
+    A2 = torch.randn(n2, d, dtype=dt, generator=gen) / d**0.5
+    V = torch.randn(n2, k, dtype=dt, generator=gen)
+    for ell in (0.7, torch.rand(d, dtype=dt, generator=gen) + 0.5):
+        want = ok.kernel_matmat(kind, A1.double(), A2.double(), ell.double() if isinstance(ell, torch.Tensor) else ell,
+                                V.double(), 1.5)
+        got = cbind.kernel_matmat(kind, A1, A2, ell, V, 1.5)
+        assert got.dtype == dt
+        lim = 1e-5 if dt == torch.float32 else 1e-12
+        assert float((got.double() - want).norm() / want.norm()) < lim
+    with pytest.raises(ValueError):
+        cbind.kernel_matmat(kind, A1[:0], A2, 1.0, V)
