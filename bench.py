@@ -83,7 +83,12 @@ def cpu_baseline(X, n, d, r, callback_freq, dev, budget_s=30.0):
        that very system (same Omega) on the GPU, timed the same way."""
     from oracle import cbind, krr
 
-    cores = cbind.num_threads()
+    # threads = the CPUs this process is entitled to (affinity capped by the cgroup quota: a one-GPU box is a
+    # 16-CPU share of a 256-thread host, and threads beyond the quota are only throttled)
+    cores = min(cbind.host_cpus(), cbind.num_threads())
+    cbind.set_num_threads(cores)
+    torch_threads = torch.get_num_threads()
+    torch.set_num_threads(cores)
     dt = X.dtype
     V = torch.ones(n, 1, dtype=dt)
     rows, spent = 256, 0.0
@@ -109,8 +114,8 @@ def cpu_baseline(X, n, d, r, callback_freq, dev, budget_s=30.0):
         "gpair_per_s": pair_rate / 1e9,
     }
     # ---- the measured solve ---------------------------------------------------------------------------------
-    # The float32 kernel matrix is written once by the C closed forms and every product is an MKL sgemv / sgemm
-    # over it: the FASTER of the two host paths (the matrix-free product the reference's pykeops CPU backend takes
+    # The float32 kernel matrix is written once by the C closed forms and every product streams it (C/OpenMP rows;
+    # MKL gemm for the sketch): the FASTER of the two host paths (the matrix-free product the reference's pykeops CPU backend takes
     # would spend n^2 (d + 24) flops per iteration instead of streaming n^2 words).  A first rung (n = 6 000) is
     # timed; the solve reported is the largest rung of the ladder whose cost, scaled by n^2 from the first, fits
     # the budget (n = 50 000 is BASELINE.json's configs[1]).
@@ -133,8 +138,8 @@ def cpu_baseline(X, n, d, r, callback_freq, dev, budget_s=30.0):
     reg = 1e-6 * n_cpu
     out["solve"] = {
         "workload": f"rbf_krr_pcg n={n_cpu} d={d} k=1 nystrom_rank={r_c} reg=1e-6*n rtol=1e-6 {str(dt)[6:]}",
-        "host_path": "dense K written once (oracle/rk_oracle.c closed forms, OpenMP) + MKL sgemv/sgemm + "
-                     "oracle Nystrom / block PCG / LinSys loop (oracle/krr.py)",
+        "host_path": "dense K written once (oracle/rk_oracle.c closed forms, OpenMP); products by the C row-streaming "
+                     "kernel (k <= 16) / MKL gemm (sketch); oracle Nystrom / block PCG / LinSys loop (oracle/krr.py)",
         "iters": int(ref["iters"]), "rel_res": float(ref["rel_res"][0]), "wall_s": round(wall, 3),
         "nystrom_build_s": round(ref["build_s"], 3), "loop_s": round(ref["loop_s"], 3),
         "iters_per_s": ref["iters"] / ref["loop_s"], "products": ref["products"], "cores": cores,
@@ -157,6 +162,7 @@ def cpu_baseline(X, n, d, r, callback_freq, dev, budget_s=30.0):
                                                        callback_freq=callback_freq)
     torch.cuda.synchronize()
     gwall = time.time() - t0
+    torch.set_num_threads(torch_threads)
     last_it = max(log)
     out["gpu_same_system"] = {
         "iters": int(last_it), "rel_res": float(log[last_it]["metrics"]["internal_metrics"]["rel_res"][0]),

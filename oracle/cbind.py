@@ -28,6 +28,13 @@ def load():
             fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                            ctypes.c_int64, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p,
                            ctypes.c_double, ctypes.c_void_p]
+        for name in ("rk_oracle_dense_matmat_f32", "rk_oracle_dense_matmat_f64"):
+            fn = getattr(_lib, name)
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                           ctypes.c_void_p]
+        _lib.rk_oracle_set_num_threads.argtypes = [ctypes.c_int]
+        _lib.rk_oracle_set_num_threads.restype = None
         _lib.rk_oracle_num_threads.restype = ctypes.c_int
     return _lib
 
@@ -72,3 +79,36 @@ def kernel_matrix(kind, X1, X2, lengthscale, const_scaling=1.0):
     if rc != 0:
         raise ValueError("rk_oracle_kernel_matrix: bad arguments")
     return K
+
+
+def dense_matmat(K, V):
+    """K @ V for a dense row-major K and at most 16 columns of V, on the host cores (OpenMP)."""
+    lib = load()
+    V2 = (V[:, None] if V.ndim == 1 else V).contiguous()
+    if not K.is_contiguous() or K.dtype != V2.dtype or K.shape[1] != V2.shape[0] or V2.shape[1] > 16:
+        raise ValueError("dense_matmat: K must be contiguous, of V's dtype and shape, with at most 16 columns in V")
+    Y = torch.empty((K.shape[0], V2.shape[1]), dtype=K.dtype)
+    fn = lib.rk_oracle_dense_matmat_f32 if K.dtype == torch.float32 else lib.rk_oracle_dense_matmat_f64
+    if fn(K.data_ptr(), K.shape[0], K.shape[1], V2.data_ptr(), V2.shape[1], Y.data_ptr()) != 0:
+        raise ValueError("rk_oracle_dense_matmat: bad arguments")
+    return Y[:, 0] if V.ndim == 1 else Y
+
+
+def host_cpus() -> int:
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box gives
+    one GPU's share of a 256-thread host; threads beyond the quota only get throttled)."""
+    import math
+    import os
+
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def set_num_threads(t: int) -> None:
+    load().rk_oracle_set_num_threads(int(t))

@@ -36,7 +36,8 @@ class KernelOperator:
     def __matmul__(self, V):
         t = time.perf_counter()
         if self.K is not None:
-            out = self.K @ V
+            # (few columns: the C row-streaming product; the sketch product: BLAS gemm)
+            out = cbind.dense_matmat(self.K, V) if (V.ndim == 1 or V.shape[1] <= 16) else self.K @ V
         else:
             out = cbind.kernel_matmat(self.kind, self.X, self.X, self.ell, V, self.scale)
         self.product_s += time.perf_counter() - t

@@ -74,7 +74,7 @@
         _Pragma("omp parallel") {                                                                \
             T* w = (T*)malloc((size_t)d * sizeof(T));                                           \
             for (int64_t c = 0; c < d; ++c) w[c] = (T)1 / (ell_vec ? ell_vec[c] : (T)ell);      \
-            _Pragma("omp for schedule(dynamic, 8)") for (int64_t i = 0; i < n1; ++i) {          \
+            _Pragma("omp for schedule(static)") for (int64_t i = 0; i < n1; ++i) {              \
                 const T* xi = X1 + i * d;                                                       \
                 for (int64_t j = 0; j < n2; ++j) {                                              \
                     const T* y = X2 + j * d;                                                    \
@@ -110,6 +110,41 @@ DEFINE_ORACLE_MATRIX(rk_oracle_kernel_matrix_f32, float, expf, sqrtf, fabsf)
 DEFINE_ORACLE_MATRIX(rk_oracle_kernel_matrix_f64, double, exp, sqrt, fabs)
 DEFINE_ORACLE(rk_oracle_kernel_matmat_f32, float, expf, sqrtf, fabsf)
 DEFINE_ORACLE(rk_oracle_kernel_matmat_f64, double, exp, sqrt, fabs)
+
+/* Y (n1 x k) = K (n1 x n2, row-major) @ V (n2 x k), k <= 16: the host's product with a kernel matrix that was
+ * written out once (rows are dealt to the threads exactly as rk_oracle_kernel_matrix_* wrote them, so a thread
+ * streams the pages it touched first).  Accumulation in the working type, 16 partial sums per row (omp simd). */
+#define DEFINE_DENSE_MATMAT(NAME, T)                                                             \
+    int NAME(const T* K, int64_t n1, int64_t n2, const T* V, int64_t k, T* Y) {                  \
+        if (n1 <= 0 || n2 <= 0 || k <= 0 || k > 16) return -1;                                   \
+        _Pragma("omp parallel for schedule(static)") for (int64_t i = 0; i < n1; ++i) {          \
+            const T* row = K + i * n2;                                                           \
+            if (k == 1) {                                                                        \
+                T s = 0;                                                                         \
+                _Pragma("omp simd reduction(+ : s)")                                             \
+                for (int64_t j = 0; j < n2; ++j) s += row[j] * V[j];                             \
+                Y[i] = s;                                                                        \
+            } else {                                                                             \
+                T acc[16];                                                                       \
+                for (int64_t c = 0; c < k; ++c) acc[c] = 0;                                      \
+                for (int64_t j = 0; j < n2; ++j) {                                               \
+                    const T a = row[j];                                                          \
+                    for (int64_t c = 0; c < k; ++c) acc[c] += a * V[j * k + c];                  \
+                }                                                                                \
+                for (int64_t c = 0; c < k; ++c) Y[i * k + c] = acc[c];                           \
+            }                                                                                    \
+        }                                                                                        \
+        return 0;                                                                                \
+    }
+
+DEFINE_DENSE_MATMAT(rk_oracle_dense_matmat_f32, float)
+DEFINE_DENSE_MATMAT(rk_oracle_dense_matmat_f64, double)
+
+void rk_oracle_set_num_threads(int t) {
+#ifdef _OPENMP
+    if (t > 0) omp_set_num_threads(t);
+#endif
+}
 
 int rk_oracle_num_threads(void) {
 #ifdef _OPENMP
