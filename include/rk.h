@@ -164,6 +164,19 @@ int rk_symm_matmat(int dtype, int store_dtype, const void* Kp, int64_t n, int64_
                    double diag_shift, void* Y, int64_t ldy, void* ws, size_t ws_bytes,
                    void* stream);
 
+/* Wide product with the packed matrix: Y (n x k) = alpha * (this rank's partial of) K V for 17 <= k <= 1024
+ * columns - the Nystrom sketch product Y = K Omega (rlaopt/preconditioners/nystrom.py:79-80, the one
+ * n x n x r product of a solve; the reference sends Omega through its worker queues,
+ * rlaopt/linops/base.py:202-267).  float32 storage and vectors.  The strips are read in place (no row-major
+ * panels); both factors are split into two float16 pieces (three exact products on the 16-bit matrix
+ * cores, float32 accumulation, entry error <= 2.4e-7 relative; RK_SYMGEMM_SPLIT=bf16x3: three bfloat16
+ * pieces, six products, float32-exact).  kmax: an upper bound on the stored entries' magnitude (the
+ * operator's const_scaling: kernel values are <= 1).  Overwrites Y. */
+size_t rk_symm_gemm_ws_bytes(int64_t n, int64_t k);
+int rk_symm_gemm(const void* Kp, int64_t n, int64_t strip_first, int64_t strip_stride, double kmax,
+                 const void* V, int64_t k, int64_t ldv, double alpha, void* Y, int64_t ldy, void* ws,
+                 size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * SAP step size  [a12]
  *

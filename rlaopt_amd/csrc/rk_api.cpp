@@ -20,4 +20,4 @@ void clear_error() { g_err[0] = '\0'; }
 }  // namespace rk
 
 extern "C" const char* rk_last_error(void) { return rk::g_err; }
-extern "C" int rk_abi_version(void) { return 14; }
+extern "C" int rk_abi_version(void) { return 15; }

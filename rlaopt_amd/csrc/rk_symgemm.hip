@@ -1,0 +1,510 @@
+// Wide products with a strip-packed symmetric kernel matrix, straight from the resident strips:
+//
+//     Y (n x r) = K V,   K = K(X, X) stored as the packed upper triangle of rk_symm.hip (float32),
+//                        r = 17 .. 1024 columns (the Nystrom sketch  Y = K Omega,
+//                        rlaopt/preconditioners/nystrom.py:79-80 - the one n x n x r product of a solve)
+//
+// on the double-rate 16-bit matrix cores at float32 accuracy.  Before this kernel the sketch product wrote
+// temporary row-major panels of K (a second evaluation of every entry: 182 ms at n = 200 000) and
+// multiplied them on the float32 matrix cores (358 ms at 115 TFLOP/s, 73 % of their peak).
+//
+// Arithmetic.  Both factors are split into 16-bit pieces whose products the matrix cores form exactly and
+// accumulate in float32:
+//   * default: TWO float16 pieces (round to nearest), x 2^e = h + m + O(2^-22 |x|); three products
+//     h.h + h.m + m.h per pair (the dropped m.m is below 2^-22 relative).  Both factors are first scaled by
+//     a power of two (K: from the caller's bound on its entries; V: from its largest entry, found on the
+//     device) so that the pieces sit in float16's normal range; the result is unscaled exactly.  Entry error
+//     <= 2.4e-7 |x| - four float32 ulps, far inside what a float32 accumulation over n = 200 000 terms
+//     carries - for half the matrix-core time of
+//   * RK_SYMGEMM_SPLIT=bf16x3: THREE bfloat16 pieces, six products (the split of rk_kernelbf16.hip:
+//     below 2^-23 relative, the rounding level of float32 itself).
+//
+// Work.  A workgroup owns 128 rows of Y and TN = 256 (or 128) of its columns and walks the whole
+// contraction j = 0 .. n in steps of 32, ascending - every workgroup in the same order, so the V tiles of a
+// step are shared through L2 by everything resident.  K[i][j] for the rows of row block I comes
+//   * j in the strip that holds I's own columns, rows above its diagonal block: TRANSPOSED tiles of that
+//     strip (lane <-> row i, 8 dword loads down the strip's rows: 256 contiguous bytes per load and wave);
+//   * j from I's diagonal block on: DIRECT tiles, rows I of every later strip (128 contiguous bytes per row).
+// Every stored entry is read twice over the whole launch (once per use; the two workgroups that share a
+// tile's rows sit on one XCD), nothing is accumulated across workgroups: no atomics, no partial tables,
+// bitwise reproducible.  With cyclically dealt strips (one rank per GPU) a rank forms the contributions of
+// ITS strips to every row block: the partials of the ranks add up to K V.
+//
+// Per step and workgroup: the K tile is loaded to registers, scaled, split and written to LDS in operand
+// layout (row-major 64-byte rows, 16-byte chunks XOR-swizzled: conflict-free ds_read_b128 for the
+// 16-row x 4-chunk operand fetch); the V tile is a linear copy of a pre-split, pre-swizzled image written
+// once per call.  Two LDS buffers, loads two steps ahead in registers, one barrier per step.  Waves: 2 x 2,
+// each 64 rows x TN / 2 columns = 4 x NCB accumulator blocks of v_mfma_f32_16x16x32_{f16,bf16}.
+#include <atomic>
+#include <stdlib.h>
+
+#include "rk_common.h"
+
+namespace rk {
+
+struct SgLayout {  // the packed layout of rk_symm.hip for float32 storage (W = 256)
+    int64_t n, first, stride;
+    static constexpr int W = 256;
+    __host__ __device__ int64_t strips_total() const { return (n + W - 1) / W; }
+    __host__ __device__ int64_t strips_local() const {
+        const int64_t S = strips_total();
+        return first < S ? (S - first + stride - 1) / stride : 0;
+    }
+    __host__ __device__ int64_t row_offset(int64_t t) const {
+        return (int64_t)W * (t * (first + 1) + stride * (t * (t - 1) / 2));
+    }
+};
+
+typedef unsigned int sg_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int sg_u2 __attribute__((ext_vector_type(2)));
+typedef float sg_acc __attribute__((ext_vector_type(4)));
+typedef _Float16 sg_h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 sg_b8 __attribute__((ext_vector_type(8)));
+
+constexpr int SG_TM = 128;   // rows of Y per workgroup
+constexpr int SG_KT = 32;    // contraction per step
+constexpr int SG_ROWB = 64;  // bytes of one operand row in LDS (32 x 16 bit)
+constexpr int SG_FOLD = 16;  // steps between folds of the running sums (a power of two; RK_SYMGEMM_FOLD overrides)
+
+// swizzle of the 16-byte chunks of an operand row: chunk q of row r sits at q ^ ((-(r >> 2)) & 3).  For the
+// four 16-lane groups in which the hardware serves a wave's ds_read_b128 (lanes {0-3, 12-15, 20-27}, ...)
+// the 16 (row, chunk) pairs of an MFMA operand fetch then fall into 16 distinct 16-byte slots of the
+// 256-byte bank row.
+__host__ __device__ __forceinline__ int sg_swz(int r, int q) { return q ^ ((0 - (r >> 2)) & 3); }
+
+// ---- piece formats ----------------------------------------------------------------------------------
+struct SgF16 {  // two float16 pieces, three products
+    static constexpr int NS = 2;
+    static constexpr bool SCALED = true;
+    // pieces of two values, packed (low half = first value)
+    __device__ static __forceinline__ void split2(float a, float b, unsigned* out) {
+        const _Float16 ha = (_Float16)a, hb = (_Float16)b;  // round to nearest even
+        const float ra = a - (float)ha, rb = b - (float)hb;  // exact
+        const _Float16 ma = (_Float16)ra, mb = (_Float16)rb;
+        out[0] = (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+        out[1] = (unsigned)__builtin_bit_cast(unsigned short, ma) | ((unsigned)__builtin_bit_cast(unsigned short, mb) << 16);
+    }
+    __device__ static __forceinline__ sg_acc mfma(sg_u4 a, sg_u4 b, sg_acc c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sg_h8, a), __builtin_bit_cast(sg_h8, b), c, 0, 0, 0);
+    }
+};
+struct SgBf16 {  // three bfloat16 pieces, six products
+    static constexpr int NS = 3;
+    static constexpr bool SCALED = false;
+    __device__ static __forceinline__ unsigned rn(float x) {
+        unsigned u = __float_as_uint(x);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return u >> 16;
+    }
+    __device__ static __forceinline__ void split1(float x, unsigned* p) {
+        p[0] = rn(x);
+        const float r1 = x - __uint_as_float(p[0] << 16);
+        p[1] = rn(r1);
+        const float r2 = r1 - __uint_as_float(p[1] << 16);
+        p[2] = rn(r2);
+    }
+    __device__ static __forceinline__ void split2(float a, float b, unsigned* out) {
+        unsigned pa[3], pb[3];
+        split1(a, pa);
+        split1(b, pb);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) out[p] = pa[p] | (pb[p] << 16);
+    }
+    __device__ static __forceinline__ sg_acc mfma(sg_u4 a, sg_u4 b, sg_acc c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sg_b8, a), __builtin_bit_cast(sg_b8, b), c, 0, 0, 0);
+    }
+};
+
+// ---- prologue 1: largest |V[:, c]| per column (device array, as float bits: non-negative floats order like
+// integers).  info = [ absmax bits (kpad) | 2^eB per column (kpad) | alpha 2^-(eA + eB) per column (kpad) ] ----
+constexpr int SG_INFO_BYTES = 3 * 1024 * 4;  // kpad <= 1024
+__global__ void __launch_bounds__(256)
+sg_absmax_kernel(const float* __restrict__ V, int64_t n, int64_t k, int64_t ldv, unsigned* __restrict__ out) {
+    const int64_t c = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    if (c >= k) return;
+    float m = 0.f;
+    for (int64_t r = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.y * 4) {
+        const float v = fabsf(V[r * ldv + c]);
+        m = (v == v && v > m) ? v : m;
+    }
+    if (m > 0.f) atomicMax(out + c, __float_as_uint(m));
+}
+
+// scale factors per column: info[kpad + c] <- 2^eB, info[2 kpad + c] <- alpha 2^-(eA + eB)
+__global__ void sg_scale_kernel(unsigned* __restrict__ info, int64_t kpad, int ea, float alpha, int scaled) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= kpad) return;
+    int eb = 0;
+    if (scaled) {
+        const float m = __uint_as_float(info[c]);
+        if (m > 0.f && m < 3.0e38f) {
+            int ex;
+            frexpf(m, &ex);  // m = f 2^ex, f in [0.5, 1): m <= 2^ex
+            eb = 14 - ex;
+            eb = eb > 100 ? 100 : (eb < -100 ? -100 : eb);
+        }
+    }
+    info[kpad + c] = __float_as_uint(ldexpf(1.f, eb));
+    info[2 * kpad + c] = __float_as_uint(alpha * ldexpf(1.f, -eb) * ldexpf(1.f, -ea));
+}
+
+// ---- prologue 2: the split image of V -----------------------------------------------------------------
+// image[step = j / 32][column tile][piece][column in tile][32 halves, chunks swizzled]; rows >= n and
+// columns >= k are zero.  One thread per (column, 8-row chunk).
+template <typename F>
+__global__ void __launch_bounds__(256)
+sg_split_rhs_kernel(const float* __restrict__ V, int64_t n, int64_t npad, int64_t k, int64_t kpad, int64_t ldv,
+                    int tn, const unsigned* __restrict__ info, unsigned char* __restrict__ img) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t col = g % kpad;
+    const int64_t chunk_all = g / kpad;  // 8-row chunk index over npad / 8
+    if (chunk_all >= npad / 8) return;
+    const float sb = F::SCALED ? __uint_as_float(info[kpad + col]) : 1.f;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int64_t j = chunk_all * 8 + e;
+        x[e] = (j < n && col < k) ? V[j * ldv + col] * sb : 0.f;
+    }
+    unsigned pk[4][F::NS];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) F::split2(x[2 * e], x[2 * e + 1], pk[e]);
+    const int64_t step = chunk_all / 4;
+    const int q = (int)(chunk_all % 4);
+    const int64_t ct = col / tn;
+    const int cl = (int)(col % tn);
+    const int64_t nct = kpad / tn;
+    unsigned char* base = img + ((step * nct + ct) * F::NS) * (int64_t)tn * SG_ROWB + cl * SG_ROWB + (sg_swz(cl, q) << 4);
+#pragma unroll
+    for (int p = 0; p < F::NS; ++p) {
+        sg_u4 o;
+        o.x = pk[0][p]; o.y = pk[1][p]; o.z = pk[2][p]; o.w = pk[3][p];
+        *reinterpret_cast<sg_u4*>(base + (int64_t)p * tn * SG_ROWB) = o;
+    }
+}
+
+// ---- the product ----------------------------------------------------------------------------------------
+template <typename F, int NCB>
+__global__ void __launch_bounds__(256, 1)
+symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __restrict__ img, int64_t nct,
+               float sa, const unsigned* __restrict__ info, int64_t k, float* __restrict__ Y, int64_t ldy,
+               int fold_mask) {
+    constexpr int NS = F::NS;
+    constexpr int TN = 32 * NCB;
+    constexpr int W = SgLayout::W;
+    constexpr int ABYTES = SG_TM * SG_ROWB;     // one piece of the K tile: 8 KiB
+    constexpr int BBYTES = TN * SG_ROWB;        // one piece of the V tile
+    constexpr int NBQ = NS * BBYTES / 16 / 256;  // 16-byte chunks of the V tile per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* AL = smem;                       // [2][NS][ABYTES]
+    unsigned char* BL = smem + 2 * NS * ABYTES;     // [2][NS][BBYTES]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    // workgroup id -> (row block, column tile): the column tiles of a row block are 8 ids apart - one XCD
+    // under round-robin placement (speed only) - and start together
+    const int64_t grp = (int64_t)blockIdx.x / (8 * nct);
+    const int64_t rem = (int64_t)blockIdx.x % (8 * nct);
+    const int64_t rb = grp * 8 + (rem & 7);
+    const int64_t ct = rem >> 3;
+    const int64_t i0 = rb * SG_TM;
+    if (i0 >= L.n) return;  // (uniform, before any barrier)
+    const int64_t b = i0 / W;            // the strip that holds this row block's columns
+    const int ioff = (int)(i0 - b * W);  // 0 or 128
+    const int64_t T = L.strips_local();
+    const bool own = b >= L.first && (b - L.first) % L.stride == 0;
+    const int64_t tb = own ? (b - L.first) / L.stride : 0;
+    const int64_t t_min = b <= L.first ? 0 : (b - L.first + L.stride - 1) / L.stride;
+    const int64_t nT = own ? b * (W / SG_KT) : 0;
+    const int64_t nD = t_min < T ? (T - t_min) * (W / SG_KT) : 0;
+
+    sg_acc acc[4][NCB];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < NCB; ++c)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[r][c][v] = 0.f;
+
+    // two-level running sums: the matrix cores add 3 (or 6) x 32 products per step to one float32 accumulator;
+    // over n / 32 = 6 250 steps the rounding of that one long chain reached 6e-5 relative (measured at
+    // n = 200 000).  The accumulators are folded into a second set every SG_FOLD steps: two short chains.
+    sg_acc tot[4][NCB];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < NCB; ++c)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) tot[r][c][v] = 0.f;
+    auto fold = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+                tot[r][c] += acc[r][c];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[r][c][v] = 0.f;
+            }
+    };
+
+    float araw[16];
+    sg_u4 braw[NBQ];
+
+    // ---- loads of one step into registers ----------------------------------------------------------
+    auto load_b = [&](int64_t jstep) {
+        const sg_u4* src = reinterpret_cast<const sg_u4*>(img + ((jstep * nct + ct) * NS) * (int64_t)BBYTES);
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) braw[q] = src[tid + 256 * q];
+    };
+    // transposed step q: rows j = 32 q .. + 32 of strip b, columns ioff + (0 .. 127): lane <-> column
+    auto load_t = [&](int64_t q) {
+        const float* base = Kp + (L.row_offset(tb) + q * SG_KT) * W + ioff + (tid & 127);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int c = (tid >> 7) + 2 * u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) araw[u * 8 + e] = __builtin_nontemporal_load(base + (int64_t)(c * 8 + e) * W);
+        }
+        load_b(q);
+    };
+    // direct step q: local strip t_min + q / 8, its columns 32 (q % 8) .. + 32, rows i0 .. i0 + 127
+    auto load_d = [&](int64_t q) {
+        const int64_t t = t_min + q / (W / SG_KT);
+        const int kk = (int)(q % (W / SG_KT)) * SG_KT;
+        const int64_t s = L.first + t * L.stride;
+        const float* base = Kp + L.row_offset(t) * W + kk + (tid & 7) * 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int64_t row = i0 + u * 32 + (tid >> 3);
+            row = row < L.n ? row : L.n - 1;  // (rows past n: finite stand-ins, never stored)
+            const sg_u4 v = __builtin_nontemporal_load(reinterpret_cast<const sg_u4*>(base + row * W));
+            araw[u * 4 + 0] = __uint_as_float(v.x); araw[u * 4 + 1] = __uint_as_float(v.y);
+            araw[u * 4 + 2] = __uint_as_float(v.z); araw[u * 4 + 3] = __uint_as_float(v.w);
+        }
+        load_b(s * (W / SG_KT) + kk / SG_KT);
+    };
+    // ---- registers -> LDS (scale, split, operand layout) ------------------------------------------------
+    auto store_b = [&](int buf) {
+        sg_u4* dst = reinterpret_cast<sg_u4*>(BL + buf * NS * BBYTES);
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) dst[tid + 256 * q] = braw[q];
+    };
+    auto store_t = [&](int buf) {
+        unsigned char* al = AL + buf * NS * ABYTES;
+        const int i = tid & 127;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int c = (tid >> 7) + 2 * u;
+            unsigned pk[4][NS];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                F::split2(araw[u * 8 + 2 * e] * (F::SCALED ? sa : 1.f), araw[u * 8 + 2 * e + 1] * (F::SCALED ? sa : 1.f), pk[e]);
+            unsigned char* dst = al + i * SG_ROWB + (sg_swz(i, c) << 4);
+#pragma unroll
+            for (int p = 0; p < NS; ++p) {
+                sg_u4 o;
+                o.x = pk[0][p]; o.y = pk[1][p]; o.z = pk[2][p]; o.w = pk[3][p];
+                *reinterpret_cast<sg_u4*>(dst + p * ABYTES) = o;
+            }
+        }
+        store_b(buf);
+    };
+    auto store_d = [&](int buf) {
+        unsigned char* al = AL + buf * NS * ABYTES;
+        const int c16 = tid & 7;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = u * 32 + (tid >> 3);
+            unsigned pk[2][NS];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                F::split2(araw[u * 4 + 2 * e] * (F::SCALED ? sa : 1.f), araw[u * 4 + 2 * e + 1] * (F::SCALED ? sa : 1.f), pk[e]);
+            unsigned char* dst = al + row * SG_ROWB + (sg_swz(row, c16 >> 1) << 4) + (c16 & 1) * 8;
+#pragma unroll
+            for (int p = 0; p < NS; ++p) {
+                sg_u2 o;
+                o.x = pk[0][p]; o.y = pk[1][p];
+                *reinterpret_cast<sg_u2*>(dst + p * ABYTES) = o;
+            }
+        }
+        store_b(buf);
+    };
+    // ---- one step of matrix-core work out of LDS ----------------------------------------------------------
+    const int a_off = (wr * 64 + lr) * SG_ROWB + (sg_swz(lr, lq) << 4);               // + rbk * 16 rows
+    const int b_off = (wc * (TN / 2) + lr) * SG_ROWB + (sg_swz(lr, lq) << 4);         // + cb * 16 columns
+    auto compute = [&](int buf) {
+        const unsigned char* al = AL + buf * NS * ABYTES + a_off;
+        const unsigned char* bl = BL + buf * NS * BBYTES + b_off;
+        sg_u4 af[4][NS];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int p = 0; p < NS; ++p)
+                af[r][p] = *reinterpret_cast<const sg_u4*>(al + r * 16 * SG_ROWB + p * ABYTES);
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            sg_u4 bf[NS];
+#pragma unroll
+            for (int p = 0; p < NS; ++p) bf[p] = *reinterpret_cast<const sg_u4*>(bl + c * 16 * SG_ROWB + p * BBYTES);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // small terms first: piece indices (pa, pb) with pa + pb = NS - 1 down to 0
+#pragma unroll
+                for (int sum = NS - 1; sum >= 0; --sum)
+#pragma unroll
+                    for (int pa = 0; pa <= sum; ++pa) acc[r][c] = F::mfma(af[r][pa], bf[sum - pa], acc[r][c]);
+            }
+        }
+    };
+
+    // ---- phase 1: transposed tiles ------------------------------------------------------------------------
+    if (nT > 0) {
+        load_t(0);
+        store_t(0);
+        load_t(nT > 1 ? 1 : 0);
+        __syncthreads();
+        for (int64_t q = 0; q < nT; ++q) {
+            const int buf = (int)(q & 1);
+            store_t(buf ^ 1);                          // step q + 1 (past the end: the last one again, unused)
+            load_t(q + 2 < nT ? q + 2 : nT - 1);
+            compute(buf);
+            if (((int)q & fold_mask) == fold_mask) fold();
+            __syncthreads();
+        }
+    }
+    // ---- phase 2: direct tiles ------------------------------------------------------------------------------
+    if (nD > 0) {
+        load_d(0);
+        store_d(0);
+        load_d(nD > 1 ? 1 : 0);
+        __syncthreads();
+        for (int64_t q = 0; q < nD; ++q) {
+            const int buf = (int)(q & 1);
+            store_d(buf ^ 1);
+            load_d(q + 2 < nD ? q + 2 : nD - 1);
+            compute(buf);
+            if (((int)q & fold_mask) == fold_mask) fold();
+            __syncthreads();
+        }
+    }
+    // ---- epilogue: element v of a lane is Y[row 4 (lane / 16) + v][column lane % 16] of its block -----------
+    const int64_t kpad = nct * TN;
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        const int64_t col = ct * TN + wc * (TN / 2) + c * 16 + lr;
+        const float unscale = __uint_as_float(info[2 * kpad + col]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int64_t row = i0 + wr * 64 + r * 16 + 4 * lq + v;
+                if (row < L.n && col < k) Y[row * ldy + col] = (tot[r][c][v] + acc[r][c][v]) * unscale;
+            }
+    }
+}
+
+static bool sg_use_bf16x3() {
+    const char* e = getenv("RK_SYMGEMM_SPLIT");
+    return e != nullptr && (e[0] == 'b' || e[0] == '3');
+}
+static int sg_tn(int64_t k) { return k <= 128 ? 128 : 256; }
+static size_t sg_image_bytes(int64_t n, int64_t k, int ns) {
+    const int64_t npad = round_up(n, SgLayout::W);
+    const int64_t kpad = round_up(k, sg_tn(k));
+    return (size_t)(npad / SG_KT) * (size_t)kpad * SG_ROWB * ns;
+}
+
+}  // namespace rk
+
+using namespace rk;
+
+extern "C" size_t rk_symm_gemm_ws_bytes(int64_t n, int64_t k) {
+    if (n <= 0 || k <= 0) return 0;
+    return SG_INFO_BYTES + sg_image_bytes(n, k, sg_use_bf16x3() ? 3 : 2);
+}
+
+extern "C" int rk_symm_gemm(const void* Kp, int64_t n, int64_t strip_first, int64_t strip_stride, double kmax,
+                            const void* V, int64_t k, int64_t ldv, double alpha, void* Y, int64_t ldy, void* ws,
+                            size_t ws_bytes, void* stream) {
+    clear_error();
+    RK_REQUIRE(Kp && V && Y, "rk_symm_gemm: null pointer");
+    RK_REQUIRE(k <= 1024, "rk_symm_gemm: at most 1024 columns per call (got %lld)", (long long)k);
+    RK_REQUIRE(n > 0 && k > 0 && ldv >= k && ldy >= k, "rk_symm_gemm: bad sizes (n=%lld k=%lld ldv=%lld ldy=%lld)",
+               (long long)n, (long long)k, (long long)ldv, (long long)ldy);
+    RK_REQUIRE(strip_stride >= 1 && strip_first >= 0 && strip_first < strip_stride, "rk_symm_gemm: bad strip distribution");
+    RK_REQUIRE(kmax > 0.0 && kmax < 1e30, "rk_symm_gemm: kmax must bound the stored entries (got %g)", kmax);
+    RK_REQUIRE(aligned16(Kp), "rk_symm_gemm: the packed matrix must be 16-byte aligned");
+    const bool bf = sg_use_bf16x3();
+    const size_t need = rk_symm_gemm_ws_bytes(n, k);
+    if (ws == nullptr || ws_bytes < need) {
+        set_error("rk_symm_gemm: workspace %zu B < required %zu B", ws_bytes, need);
+        return RK_ERR_WORKSPACE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned* info = static_cast<unsigned*>(ws);
+    unsigned char* img = static_cast<unsigned char*>(ws) + SG_INFO_BYTES;
+    const int tn = sg_tn(k);
+    const int64_t npad = round_up(n, SgLayout::W), kpad = round_up(k, tn), nct = kpad / tn;
+    // K entries <= kmax: scaled by 2^ea they stay below 2^14 (float16 pieces in their normal range)
+    int ea = 0;
+    if (!bf) {
+        int ex;
+        frexp(kmax, &ex);
+        ea = 14 - ex;
+    }
+    if (hipMemsetAsync(info, 0, SG_INFO_BYTES, st) != hipSuccess) return launch_status("rk_symm_gemm(memset)");
+    if (!bf)
+        hipLaunchKernelGGL(sg_absmax_kernel, dim3((unsigned)ceil_div(k, 64), 512), dim3(256), 0, st, (const float*)V, n,
+                           k, ldv, info);
+    hipLaunchKernelGGL(sg_scale_kernel, dim3((unsigned)ceil_div(kpad, 256)), dim3(256), 0, st, info, kpad, ea,
+                       (float)alpha, bf ? 0 : 1);
+    const dim3 sgrid((unsigned)ceil_div((npad / 8) * kpad, 256));
+    if (bf)
+        hipLaunchKernelGGL(sg_split_rhs_kernel<SgBf16>, sgrid, dim3(256), 0, st, (const float*)V, n, npad, k, kpad, ldv, tn,
+                           info, img);
+    else
+        hipLaunchKernelGGL(sg_split_rhs_kernel<SgF16>, sgrid, dim3(256), 0, st, (const float*)V, n, npad, k, kpad, ldv, tn,
+                           info, img);
+    int rc = launch_status("rk_symm_gemm(split)");
+    if (rc != RK_OK) return rc;
+    SgLayout L{n, strip_first, strip_stride};
+    const int64_t nrb = ceil_div(n, SG_TM);
+    const dim3 grid((unsigned)(ceil_div(nrb, 8) * 8 * nct));
+    const float sa = (float)ldexp(1.0, ea);
+    int fold_steps = SG_FOLD;
+    if (const char* e = getenv("RK_SYMGEMM_FOLD")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 4096 && (v & (v - 1)) == 0) fold_steps = v;
+    }
+    const int fold_mask = fold_steps - 1;
+#define RK_SG(FMT, NCBV)                                                                                         \
+    do {                                                                                                         \
+        constexpr size_t smem = 2 * FMT::NS * (SG_TM * SG_ROWB + 32 * NCBV * SG_ROWB);                           \
+        static std::atomic<unsigned long long> attr_devs{0}; /* one bit per device ordinal */                      \
+        int dev_ = 0;                                                                                            \
+        (void)hipGetDevice(&dev_);                                                                               \
+        const unsigned long long bit_ = 1ull << (dev_ & 63);                                                     \
+        if (!(attr_devs.load(std::memory_order_acquire) & bit_)) {                                               \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(symgemm_kernel<FMT, NCBV>),                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {      \
+                (void)hipGetLastError();                                                                         \
+                set_error("rk_symm_gemm: cannot reserve %zu bytes of LDS", smem);                                \
+                return RK_ERR_LAUNCH;                                                                            \
+            }                                                                                                    \
+            attr_devs.fetch_or(bit_, std::memory_order_release);                                                 \
+        }                                                                                                        \
+        hipLaunchKernelGGL((symgemm_kernel<FMT, NCBV>), grid, dim3(256), smem, st, (const float*)Kp, L, img, nct, \
+                           sa, info, k, (float*)Y, ldy, fold_mask);                                                      \
+    } while (0)
+    if (bf) {
+        if (tn == 256) RK_SG(SgBf16, 8);
+        else RK_SG(SgBf16, 4);
+    } else {
+        if (tn == 256) RK_SG(SgF16, 8);
+        else RK_SG(SgF16, 4);
+    }
+#undef RK_SG
+    return launch_status("rk_symm_gemm");
+}

@@ -145,6 +145,23 @@ class _SymPackBlock:
             tag="kernel_shard_product",
         )
 
+    def gemm_ready(self, x) -> bool:
+        """Wide products straight from the resident strips (``rk_symm_gemm``): float32 storage, a 2-D block."""
+        return (self.store_dtype == torch.float32 and x.ndim == 2 and x.dtype in (torch.float32, torch.float64)
+                and self.scale != 0.0 and os.environ.get("RK_SYMGEMM", "1") != "0")
+
+    def partial_matmat_wide(self, x):
+        """This rank's partial of K x (all n rows) for many columns, from the packed strips in place on the
+        16-bit matrix cores - no row-major panels, no second evaluation of the entries; complete when
+        stride == 1.  float64 x over float32 storage: the product runs in float32 (as the panel route does)."""
+        be = get_backend()
+        xs = x if x.dtype == torch.float32 else x.float()
+        outs = [be.symm_gemm(self.Kp, self.n, xs[:, c0 : c0 + 1024], kmax=abs(self.scale), first=self.first,
+                             stride=self.stride, tag="kernel_sketch_product")
+                for c0 in range(0, xs.shape[1], 1024)]
+        out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
+        return out.to(x.dtype)
+
     def rows_matmat_wide(self, x, lo: int, hi: int):
         """Rows [lo, hi) of K x for many columns: temporary row-major panels + GEMM (in the
         storage dtype: with float32 storage the sketch product runs on the fp32 matrix cores)."""
@@ -321,7 +338,10 @@ class _KernelLinOp(TwoSidedLinOp, ScaleMixin):
         cols = 1 if x.ndim == 1 else x.shape[1]
         if cols <= _SYM_MAX_COLS:
             return self._sym.partial_matmat(x, diag_shift=diag_shift)
-        y = self._sym.rows_matmat_wide(x, 0, self.shape[0])
+        if self._sym.gemm_ready(x):
+            y = self._sym.partial_matmat_wide(x)  # (one device: stride 1, the partial is the product)
+        else:
+            y = self._sym.rows_matmat_wide(x, 0, self.shape[0])
         return y + diag_shift * x if diag_shift != 0.0 else y
 
     # fused "A @ X + shift * X" used by the solvers (saves one pass over X)
@@ -527,7 +547,13 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
         if cols <= _SYM_MAX_COLS:
             return self._sym_full_matmat(w).to(w.device)
         lo, hi = self.row_range
-        mine = self._sym.rows_matmat_wide(w.to(self._sym.X.device), lo, hi)
+        ws = w.to(self._sym.X.device)
+        if self._sym.gemm_ready(ws):
+            full = self._sym.partial_matmat_wide(ws)  # every row, this rank's strips
+            if self._spmd:
+                _dist.all_reduce_sum(full, self._group)
+            return full.to(w.device)
+        mine = self._sym.rows_matmat_wide(ws, lo, hi)
         if self._spmd:
             mine = _dist.all_gather_rows(mine, self.shape[0], self._group)
         return mine.to(w.device)
@@ -548,6 +574,11 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
                 if not self._spmd:  # one shard: the kernel applies the shift itself
                     return self._sym.partial_matmat(X_full.to(self._sym.X.device), diag_shift=diag_shift)
                 Y = self._sym_full_matmat(X_full)[lo:hi]
+            elif self._sym.gemm_ready(X_full):
+                Y = self._sym.partial_matmat_wide(X_full.to(self._sym.X.device))
+                if self._spmd:  # the ranks' partials add up to the product; this rank keeps its rows
+                    _dist.all_reduce_sum(Y, self._group)
+                Y = Y[lo:hi]
             else:
                 Y = self._sym.rows_matmat_wide(X_full.to(self._sym.X.device), lo, hi)
             return Y + diag_shift * X_full[lo:hi].to(Y.device) if diag_shift != 0.0 else Y

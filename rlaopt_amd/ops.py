@@ -333,6 +333,25 @@ class HipBackend:
             _lib.check(rc, "rk_symm_matmat")
         return out[:, 0] if squeeze else out
 
+    def symm_gemm(self, Kp, n, V, kmax=1.0, alpha=1.0, first=0, stride=1, tag=None):
+        """alpha * (this rank's partial of) K V for MANY columns (the sketch product Y = K Omega), from
+        the float32 packed triangle in place, on the 16-bit matrix cores (``rk_symm_gemm``).  ``kmax``
+        bounds the magnitude of the stored entries (the operator's const_scaling)."""
+        dev = _req(Kp, V)
+        if Kp.dtype != torch.float32 or V.dtype != torch.float32 or V.ndim != 2 or V.shape[0] != n:
+            raise ValueError("symm_gemm: float32 packed matrix and a float32 n x k block")
+        V2, ldv = _rowmajor(V)
+        k = V2.shape[1]
+        out = torch.empty((n, k), dtype=torch.float32, device=dev)
+        nbytes = self._lib.rk_symm_gemm_ws_bytes(n, k)
+        # (its own buffer: the split image of V is hundreds of MB - not something to pin in the shared workspace)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        with self._timed(tag or "rk_symm_gemm", dev, 2 * Kp.numel() * 4 + 2 * n * k * 4):
+            rc = self._lib.rk_symm_gemm(_ptr(Kp), n, first, stride, float(kmax), _ptr(V2), k, ldv, float(alpha),
+                                        _ptr(out), k, _ptr(ws), nbytes, _stream(dev))
+        _lib.check(rc, "rk_symm_gemm")
+        return out
+
     # -- dense products ----------------------------------------------------------------
     def matmat(self, A, V, alpha=1.0, beta=0.0, C=None, diag_shift=0.0, row0=0, tag=None):
         """alpha * A @ V + beta * C + diag_shift * V[row0 : row0 + m].  ``tag`` names the

@@ -50,6 +50,9 @@ class OracleBackend:
         Y = alpha * Y + diag_shift * V2
         return Y[:, 0] if sq else Y
 
+    def symm_gemm(self, Kp, n, V, kmax=1.0, alpha=1.0, first=0, stride=1, tag=None):
+        return self.symm_matmat(Kp, n, V, alpha=alpha, first=first, stride=stride)
+
     def matmat(self, A, V, alpha=1.0, beta=0.0, C=None, diag_shift=0.0, row0=0, tag=None):
         V2, sq = _two_d(V)
         Y = alpha * (A @ V2)

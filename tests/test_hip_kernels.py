@@ -801,3 +801,47 @@ def test_kernel_matmat_keeps_the_x2_image_between_calls(be, monkeypatch, kind, d
     c3 = {}
     be.kernel_matmat(kind, X, X, 1.0, V[:, :2].contiguous(), gram_center=gc, x2_cache=c3)
     assert "streams" not in c3
+
+
+@pytest.mark.parametrize("n,k,first,stride", [(1000, 40, 0, 1), (2304, 100, 0, 1), (3000, 256, 0, 1), (5000, 512, 0, 1),
+                                             (4100, 130, 1, 3), (2600, 64, 0, 2), (2600, 64, 1, 2), (700, 17, 0, 1)])
+@pytest.mark.parametrize("split", ["f16x2", "bf16x3"])
+def test_symm_gemm_wide_product_from_the_packed_strips(be, monkeypatch, n, k, first, stride, split):
+    """rk_symm_gemm: Y = K V for many columns straight from the float32 packed triangle (both piece formats),
+    against the float64 product with the dense kernel matrix; strips dealt cyclically: the partials of the
+    ranks add up to the product; const_scaling, a V with a wide dynamic range (per-column scales 1e-6 .. 1e3:
+    the power-of-two scaling must keep the float16 pieces exact) and bitwise reproducibility."""
+    if split == "bf16x3":
+        monkeypatch.setenv("RK_SYMGEMM_SPLIT", "bf16x3")
+    dt = torch.float32
+    d = 9
+    g = torch.Generator().manual_seed(n + k)
+    X = torch.randn(n, d, dtype=dt, generator=g) / d**0.5
+    scale = 3.5
+    V = torch.randn(n, k, dtype=dt, generator=g) * torch.logspace(-6, 3, k, dtype=dt)
+    Kd = ok.kernel_matrix("rbf", X.double(), X.double(), 1.0, scale)
+    want = Kd @ V.double()
+    Xd, Vd = X.to(dev()), V.to(dev())
+    if stride == 1:
+        Kp = be.sympack_materialize("rbf", Xd, 1.0, scale=scale)
+        got = be.symm_gemm(Kp, n, Vd, kmax=scale)
+        assert torch.equal(got, be.symm_gemm(Kp, n, Vd, kmax=scale))  # reproducible bit for bit
+        got = got.cpu().double()
+    else:
+        parts = []
+        for f in range(stride):
+            Kp = be.sympack_materialize("rbf", Xd, 1.0, scale=scale, first=f, stride=stride)
+            parts.append(be.symm_gemm(Kp, n, Vd, kmax=scale, first=f, stride=stride).cpu().double())
+        got = sum(parts)
+        if first:  # (the parametrisation only varies which rank's partial is also checked to be non-trivial)
+            assert float(parts[first].abs().max()) > 0
+    # column-wise relative error: the level of a float32 product (the float32 matrix itself carries 6e-8 per
+    # entry; the matrix cores' float32 accumulation truncates: ~1e-8 per accumulation step of a chain)
+    err = (got - want).norm(dim=0) / want.norm(dim=0)
+    assert float(err.max()) < 5e-6, (float(err.max()), int(err.argmax()))
+    # alpha, and a strided V (columns of a wider array)
+    if stride == 1:
+        wide = torch.randn(n, k + 3, dtype=dt, generator=g).to(dev())
+        got2 = be.symm_gemm(Kp, n, wide[:, 2 : 2 + k], kmax=scale, alpha=-0.5).cpu().double()
+        want2 = -0.5 * (Kd @ wide[:, 2 : 2 + k].cpu().double())
+        assert float((got2 - want2).norm() / want2.norm()) < 5e-6
