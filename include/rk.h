@@ -177,6 +177,13 @@ int rk_symm_gemm(const void* Kp, int64_t n, int64_t strip_first, int64_t strip_s
                  const void* V, int64_t k, int64_t ldv, double alpha, void* Y, int64_t ldy, void* ws,
                  size_t ws_bytes, void* stream);
 
+/* Wire buffer of the reduce-scatter that sums the ranks' partial products  [a5, e]: out (slots x (step k + t)),
+ * slot r = [ rows r step .. (r + 1) step of the n x k partial (zero beyond row n) | tail (t float64 values,
+ * converted) ], in `dtype`.  One launch instead of a zero-fill, a strided copy and a broadcast; the transport
+ * it feeds replaces the reference's result queue + host concat/sum (rlaopt/linops/distributed.py:40-50,81-91). */
+int rk_spmd_pack(int dtype, const void* part, int64_t n, int64_t k, int64_t ldp, const double* tail, int64_t t,
+                 int64_t step, int64_t slots, void* out, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * SAP step size  [a12]
  *

@@ -33,8 +33,10 @@
 // Per step and workgroup: the K tile is loaded to registers, scaled, split and written to LDS in operand
 // layout (row-major 64-byte rows, 16-byte chunks XOR-swizzled: conflict-free ds_read_b128 for the
 // 16-row x 4-chunk operand fetch); the V tile is a linear copy of a pre-split, pre-swizzled image written
-// once per call.  Two LDS buffers, loads two steps ahead in registers, one barrier per step.  Waves: 2 x 2,
-// each 64 rows x TN / 2 columns = 4 x NCB accumulator blocks of v_mfma_f32_16x16x32_{f16,bf16}.
+// once per call.  Two LDS buffers, loads two steps ahead in registers, one barrier per step.  Waves: 4 x 2
+// (eight per workgroup, two per SIMD: one wave's staging and waits sit beside the other's matrix-core work -
+// with four waves, one per SIMD, the matrix cores were busy 39 % of the time), each 32 rows x TN / 2 columns
+// = 2 x NCB accumulator blocks of v_mfma_f32_16x16x32_{f16,bf16}.
 #include <atomic>
 #include <stdlib.h>
 
@@ -62,6 +64,8 @@ typedef _Float16 sg_h8 __attribute__((ext_vector_type(8)));
 typedef __bf16 sg_b8 __attribute__((ext_vector_type(8)));
 
 constexpr int SG_TM = 128;   // rows of Y per workgroup
+constexpr int SG_THREADS = 512;  // 8 waves: 4 (rows) x 2 (columns)
+constexpr int SG_RB = 2;     // 16-row accumulator blocks per wave
 constexpr int SG_KT = 32;    // contraction per step
 constexpr int SG_ROWB = 64;  // bytes of one operand row in LDS (32 x 16 bit)
 constexpr int SG_FOLD = 16;  // steps between folds of the running sums (a power of two; RK_SYMGEMM_FOLD overrides)
@@ -185,7 +189,7 @@ sg_split_rhs_kernel(const float* __restrict__ V, int64_t n, int64_t npad, int64_
 
 // ---- the product ----------------------------------------------------------------------------------------
 template <typename F, int NCB>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(SG_THREADS, 2)
 symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __restrict__ img, int64_t nct,
                float sa, const unsigned* __restrict__ info, int64_t k, float* __restrict__ Y, int64_t ldy,
                int fold_mask) {
@@ -194,7 +198,7 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
     constexpr int W = SgLayout::W;
     constexpr int ABYTES = SG_TM * SG_ROWB;     // one piece of the K tile: 8 KiB
     constexpr int BBYTES = TN * SG_ROWB;        // one piece of the V tile
-    constexpr int NBQ = NS * BBYTES / 16 / 256;  // 16-byte chunks of the V tile per thread
+    constexpr int NBQ = NS * BBYTES / 16 / SG_THREADS;  // 16-byte chunks of the V tile per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* AL = smem;                       // [2][NS][ABYTES]
     unsigned char* BL = smem + 2 * NS * ABYTES;     // [2][NS][BBYTES]
@@ -202,7 +206,7 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave >> 1, wc = wave & 1;  // wr: 32-row slab, wc: column half
     // workgroup id -> (row block, column tile): the column tiles of a row block are 8 ids apart - one XCD
     // under round-robin placement (speed only) - and start together
     const int64_t grp = (int64_t)blockIdx.x / (8 * nct);
@@ -220,9 +224,9 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
     const int64_t nT = own ? b * (W / SG_KT) : 0;
     const int64_t nD = t_min < T ? (T - t_min) * (W / SG_KT) : 0;
 
-    sg_acc acc[4][NCB];
+    sg_acc acc[SG_RB][NCB];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < SG_RB; ++r)
 #pragma unroll
         for (int c = 0; c < NCB; ++c)
 #pragma unroll
@@ -231,16 +235,16 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
     // two-level running sums: the matrix cores add 3 (or 6) x 32 products per step to one float32 accumulator;
     // over n / 32 = 6 250 steps the rounding of that one long chain reached 6e-5 relative (measured at
     // n = 200 000).  The accumulators are folded into a second set every SG_FOLD steps: two short chains.
-    sg_acc tot[4][NCB];
+    sg_acc tot[SG_RB][NCB];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < SG_RB; ++r)
 #pragma unroll
         for (int c = 0; c < NCB; ++c)
 #pragma unroll
             for (int v = 0; v < 4; ++v) tot[r][c][v] = 0.f;
     auto fold = [&]() {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < SG_RB; ++r)
 #pragma unroll
             for (int c = 0; c < NCB; ++c) {
                 tot[r][c] += acc[r][c];
@@ -249,24 +253,21 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
             }
     };
 
-    float araw[16];
+    float araw[8];
     sg_u4 braw[NBQ];
 
     // ---- loads of one step into registers ----------------------------------------------------------
     auto load_b = [&](int64_t jstep) {
         const sg_u4* src = reinterpret_cast<const sg_u4*>(img + ((jstep * nct + ct) * NS) * (int64_t)BBYTES);
 #pragma unroll
-        for (int q = 0; q < NBQ; ++q) braw[q] = src[tid + 256 * q];
+        for (int q = 0; q < NBQ; ++q) braw[q] = src[tid + SG_THREADS * q];
     };
-    // transposed step q: rows j = 32 q .. + 32 of strip b, columns ioff + (0 .. 127): lane <-> column
+    // transposed step q: rows j = 32 q .. + 32 of strip b, columns ioff + (0 .. 127): lane <-> column,
+    // thread group tid >> 7 <-> 8-row chunk
     auto load_t = [&](int64_t q) {
-        const float* base = Kp + (L.row_offset(tb) + q * SG_KT) * W + ioff + (tid & 127);
+        const float* base = Kp + (L.row_offset(tb) + q * SG_KT + (tid >> 7) * 8) * W + ioff + (tid & 127);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int c = (tid >> 7) + 2 * u;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) araw[u * 8 + e] = __builtin_nontemporal_load(base + (int64_t)(c * 8 + e) * W);
-        }
+        for (int e = 0; e < 8; ++e) araw[e] = __builtin_nontemporal_load(base + (int64_t)e * W);
         load_b(q);
     };
     // direct step q: local strip t_min + q / 8, its columns 32 (q % 8) .. + 32, rows i0 .. i0 + 127
@@ -276,8 +277,8 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
         const int64_t s = L.first + t * L.stride;
         const float* base = Kp + L.row_offset(t) * W + kk + (tid & 7) * 4;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int64_t row = i0 + u * 32 + (tid >> 3);
+        for (int u = 0; u < 2; ++u) {
+            int64_t row = i0 + u * 64 + (tid >> 3);
             row = row < L.n ? row : L.n - 1;  // (rows past n: finite stand-ins, never stored)
             const sg_u4 v = __builtin_nontemporal_load(reinterpret_cast<const sg_u4*>(base + row * W));
             araw[u * 4 + 0] = __uint_as_float(v.x); araw[u * 4 + 1] = __uint_as_float(v.y);
@@ -289,25 +290,21 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
     auto store_b = [&](int buf) {
         sg_u4* dst = reinterpret_cast<sg_u4*>(BL + buf * NS * BBYTES);
 #pragma unroll
-        for (int q = 0; q < NBQ; ++q) dst[tid + 256 * q] = braw[q];
+        for (int q = 0; q < NBQ; ++q) dst[tid + SG_THREADS * q] = braw[q];
     };
     auto store_t = [&](int buf) {
         unsigned char* al = AL + buf * NS * ABYTES;
-        const int i = tid & 127;
+        const int i = tid & 127, c = tid >> 7;
+        unsigned pk[4][NS];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int c = (tid >> 7) + 2 * u;
-            unsigned pk[4][NS];
+        for (int e = 0; e < 4; ++e)
+            F::split2(araw[2 * e] * (F::SCALED ? sa : 1.f), araw[2 * e + 1] * (F::SCALED ? sa : 1.f), pk[e]);
+        unsigned char* dst = al + i * SG_ROWB + (sg_swz(i, c) << 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                F::split2(araw[u * 8 + 2 * e] * (F::SCALED ? sa : 1.f), araw[u * 8 + 2 * e + 1] * (F::SCALED ? sa : 1.f), pk[e]);
-            unsigned char* dst = al + i * SG_ROWB + (sg_swz(i, c) << 4);
-#pragma unroll
-            for (int p = 0; p < NS; ++p) {
-                sg_u4 o;
-                o.x = pk[0][p]; o.y = pk[1][p]; o.z = pk[2][p]; o.w = pk[3][p];
-                *reinterpret_cast<sg_u4*>(dst + p * ABYTES) = o;
-            }
+        for (int p = 0; p < NS; ++p) {
+            sg_u4 o;
+            o.x = pk[0][p]; o.y = pk[1][p]; o.z = pk[2][p]; o.w = pk[3][p];
+            *reinterpret_cast<sg_u4*>(dst + p * ABYTES) = o;
         }
         store_b(buf);
     };
@@ -315,8 +312,8 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
         unsigned char* al = AL + buf * NS * ABYTES;
         const int c16 = tid & 7;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = u * 32 + (tid >> 3);
+        for (int u = 0; u < 2; ++u) {
+            const int row = u * 64 + (tid >> 3);
             unsigned pk[2][NS];
 #pragma unroll
             for (int e = 0; e < 2; ++e)
@@ -332,14 +329,14 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
         store_b(buf);
     };
     // ---- one step of matrix-core work out of LDS ----------------------------------------------------------
-    const int a_off = (wr * 64 + lr) * SG_ROWB + (sg_swz(lr, lq) << 4);               // + rbk * 16 rows
+    const int a_off = (wr * 16 * SG_RB + lr) * SG_ROWB + (sg_swz(lr, lq) << 4);       // + rbk * 16 rows
     const int b_off = (wc * (TN / 2) + lr) * SG_ROWB + (sg_swz(lr, lq) << 4);         // + cb * 16 columns
     auto compute = [&](int buf) {
         const unsigned char* al = AL + buf * NS * ABYTES + a_off;
         const unsigned char* bl = BL + buf * NS * BBYTES + b_off;
-        sg_u4 af[4][NS];
+        sg_u4 af[SG_RB][NS];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < SG_RB; ++r)
 #pragma unroll
             for (int p = 0; p < NS; ++p)
                 af[r][p] = *reinterpret_cast<const sg_u4*>(al + r * 16 * SG_ROWB + p * ABYTES);
@@ -349,7 +346,7 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
 #pragma unroll
             for (int p = 0; p < NS; ++p) bf[p] = *reinterpret_cast<const sg_u4*>(bl + c * 16 * SG_ROWB + p * BBYTES);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < SG_RB; ++r) {
                 // small terms first: piece indices (pa, pb) with pa + pb = NS - 1 down to 0
 #pragma unroll
                 for (int sum = NS - 1; sum >= 0; --sum)
@@ -396,10 +393,10 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
         const int64_t col = ct * TN + wc * (TN / 2) + c * 16 + lr;
         const float unscale = __uint_as_float(info[2 * kpad + col]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < SG_RB; ++r)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int64_t row = i0 + wr * 64 + r * 16 + 4 * lq + v;
+                const int64_t row = i0 + wr * 16 * SG_RB + r * 16 + 4 * lq + v;
                 if (row < L.n && col < k) Y[row * ldy + col] = (tot[r][c][v] + acc[r][c][v]) * unscale;
             }
     }
@@ -495,7 +492,7 @@ extern "C" int rk_symm_gemm(const void* Kp, int64_t n, int64_t strip_first, int6
             }                                                                                                    \
             attr_devs.fetch_or(bit_, std::memory_order_release);                                                 \
         }                                                                                                        \
-        hipLaunchKernelGGL((symgemm_kernel<FMT, NCBV>), grid, dim3(256), smem, st, (const float*)Kp, L, img, nct, \
+        hipLaunchKernelGGL((symgemm_kernel<FMT, NCBV>), grid, dim3(SG_THREADS), smem, st, (const float*)Kp, L, img, nct, \
                            sa, info, k, (float*)Y, ldy, fold_mask);                                                      \
     } while (0)
     if (bf) {

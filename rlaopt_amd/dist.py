@@ -64,9 +64,26 @@ def my_rows(n: int, group=None) -> tuple[int, int]:
     return chunks[rank] if rank < len(chunks) else (n, n)
 
 
+# What went over the wire since the last ``reset_wire_stats`` (ring accounting: an all-reduce of b bytes
+# sends 2 (p - 1) / p b per rank, a reduce-scatter or an all-gather of b bytes in total (p - 1) / p b).
+wire_stats = {"collectives": 0, "bytes_sent_per_rank": 0.0, "by_kind": {}}
+
+
+def reset_wire_stats() -> None:
+    wire_stats.update(collectives=0, bytes_sent_per_rank=0.0, by_kind={})
+
+
+def _account(kind: str, nbytes: int, factor: float, group) -> None:
+    size = td.get_world_size(group)
+    wire_stats["collectives"] += 1
+    wire_stats["bytes_sent_per_rank"] += factor * (size - 1) / max(size, 1) * nbytes
+    wire_stats["by_kind"][kind] = wire_stats["by_kind"].get(kind, 0) + 1
+
+
 def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     """In-place sum over ranks (no-op without a group)."""
     if spmd_active(group):
+        _account("all_reduce", t.numel() * t.element_size(), 2.0, group)
         if _host_staged(t, group):
             h = t.cpu()
             td.all_reduce(h, op=td.ReduceOp.SUM, group=group)
@@ -104,6 +121,7 @@ def all_gather_rows(local: torch.Tensor, sizes, group=None) -> torch.Tensor:
         pad = torch.zeros((step, k), dtype=loc.dtype, device=loc.device)
         pad[: loc.shape[0]] = loc
         loc = pad
+    _account("all_gather", size * step * k * loc.element_size(), 1.0, group)
     if _host_staged(loc, group):
         host = torch.empty((size * step, k), dtype=loc.dtype)
         td.all_gather_into_tensor(host, loc.cpu().contiguous(), group=group)
@@ -117,6 +135,37 @@ def all_gather_rows(local: torch.Tensor, sizes, group=None) -> torch.Tensor:
     else:
         out = torch.cat([out[r * step : r * step + sizes[r]] for r in range(size)], dim=0)
     return out[:, 0] if squeeze else out
+
+
+def reduce_scatter_rows(partial: torch.Tensor, n: int, tail: torch.Tensor | None = None, group=None):
+    """Sum the ranks' full-length partials (n x k each) and leave every rank with ITS rows of the sum
+    (``row_chunks`` partition), plus - when ``tail`` is given - the sum of the ranks' small ``tail``
+    blocks on every rank, all in ONE reduce-scatter: the wire buffer has one slot per rank, slot r =
+    [rows of rank r, padded to the tallest block | tail], in the dtype of ``partial`` (``rk_spmd_pack``:
+    one launch).  Against an all-reduce of the whole partial this sends half the bytes per element and -
+    for float32 partials that used to ride in a float64 buffer next to a float64 tail - a quarter.
+    Returns (rows, tail_sum) with tail_sum in float64 (None without a tail); no-op without a group."""
+    from .ops import get_backend
+
+    rank, size = world(group)
+    if not spmd_active(group):
+        return partial, (None if tail is None else tail.double())
+    sizes = chunk_sizes(n, group)
+    step = max(sizes)
+    k = partial.shape[1]
+    t = 0 if tail is None else tail.numel()
+    slot = step * k + t
+    buf = get_backend().spmd_pack(partial, n, step, size, tail)  # (size, slot)
+    _account("reduce_scatter", size * slot * buf.element_size(), 1.0, group)
+    if _host_staged(buf, group):
+        host = torch.empty(slot, dtype=buf.dtype)
+        td.reduce_scatter_tensor(host, buf.cpu().reshape(-1), op=td.ReduceOp.SUM, group=group)
+        out = host.to(buf.device)
+    else:
+        out = torch.empty(slot, dtype=buf.dtype, device=buf.device)
+        td.reduce_scatter_tensor(out, buf.view(-1), op=td.ReduceOp.SUM, group=group)
+    rows = out[: sizes[rank] * k].view(sizes[rank], k)
+    return rows, (None if tail is None else out[step * k :].double().view(tail.shape))
 
 
 def _first_short(sizes, step):

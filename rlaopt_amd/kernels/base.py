@@ -430,6 +430,18 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
         devs = _sorted_devices(devices)
         rank, size = _dist.world(group)
         spmd = _dist.spmd_active(group)
+        if not spmd and len({(d.type, d.index) for d in devs if d.type == "cuda"}) > 1:
+            # the reference's own multi-GPU call (one process, devices={cuda:0 .. cuda:p-1},
+            # rlaopt/kernels/factory.py:34-41) is accepted, but it is not the layout this engine is built for
+            import warnings
+
+            warnings.warn(
+                f"rlaopt_amd: {len(devs)} devices in ONE process: the shards are driven from this process's launch "
+                "queues one after another, without the strip-packed symmetric storage and without RCCL, and this "
+                "mode has never run on more than one physical GPU.  For multi-GPU runs start one rank per GPU "
+                "(python -m torch.distributed.run --nproc-per-node P script.py, torch.distributed.init_process_group"
+                "('nccl')) and pass this rank's device: the operator then shards itself over the process group.",
+                RuntimeWarning, stacklevel=3)
         parts = size if spmd else len(devs)
         n1, n2 = A1.shape[0], A2.shape[0]
         # base.py:297-302: torch.chunk partition of the rows of A1 (operator) and A2 (oracle)
@@ -611,6 +623,12 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
         X_full = X_full.to(self._sym.X.device)
         part = self._sym.partial_matmat(X_full, diag_shift=shift if self._rank == 0 else 0.0)
         gram = be.rmatmat(X_full, part, out_f64=True)
+        if os.environ.get("RK_SPMD_REDUCE_SCATTER", "1") != "0":
+            # every rank keeps only its rows of the sum: a reduce-scatter of the partials in their own
+            # dtype, the k x k Gram partial riding in every slot (half the wire bytes per element of an
+            # all-reduce; a quarter for float32 partials, which used to travel in a float64 buffer)
+            Y, PAP = _dist.reduce_scatter_rows(part, n, tail=gram, group=self._group)
+            return Y, PAP
         both = torch.cat([part.reshape(-1).double(), gram.reshape(-1)])
         _dist.all_reduce_sum(both, self._group)
         Y = both[: n * k].view(n, k)[lo:hi].to(X_full.dtype)

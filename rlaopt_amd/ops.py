@@ -487,6 +487,20 @@ class HipBackend:
         _lib.check(rc, "rk_gram_tn")
         return out
 
+    def spmd_pack(self, part, n, step, slots, tail=None):
+        """(slots, step k + t) wire buffer of ``dist.reduce_scatter_rows``: slot r = [rows r step ..
+        of the n x k partial, zero padded | tail] in the partial's dtype (``rk_spmd_pack``, one launch)."""
+        dev = _req(part, tail)
+        P2, ldp = _rowmajor(part)
+        k = P2.shape[1]
+        t = 0 if tail is None else tail.numel()
+        if tail is not None and (tail.dtype != torch.float64 or not tail.is_contiguous()):
+            tail = tail.double().contiguous()
+        out = torch.empty((slots, step * k + t), dtype=P2.dtype, device=dev)
+        rc = self._lib.rk_spmd_pack(_dt(P2), _ptr(P2), n, k, ldp, _ptr(tail), t, step, slots, _ptr(out), _stream(dev))
+        _lib.check(rc, "rk_spmd_pack")
+        return out
+
     # -- block PCG pieces --------------------------------------------------------------
     def pcg_update_wr(self, W, R, P, AP, alpha):
         dev = _req(W, R, P, AP, alpha)

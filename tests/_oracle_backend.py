@@ -50,6 +50,17 @@ class OracleBackend:
         Y = alpha * Y + diag_shift * V2
         return Y[:, 0] if sq else Y
 
+    def spmd_pack(self, part, n, step, slots, tail=None):
+        k = part.shape[1]
+        t = 0 if tail is None else tail.numel()
+        out = torch.zeros((slots, step * k + t), dtype=part.dtype)
+        rows = torch.zeros((slots * step, k), dtype=part.dtype)
+        rows[:n] = part
+        out[:, : step * k] = rows.view(slots, step * k)
+        if t:
+            out[:, step * k :] = tail.reshape(-1).to(part.dtype)
+        return out
+
     def symm_gemm(self, Kp, n, V, kmax=1.0, alpha=1.0, first=0, stride=1, tag=None):
         return self.symm_matmat(Kp, n, V, alpha=alpha, first=first, stride=stride)
 

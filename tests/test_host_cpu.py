@@ -72,3 +72,21 @@ def test_nystrom_inverse_with_gram_matches_apply_then_gram(dt):
     want = X.double().T @ Zref.double()
     assert XtZ.dtype == torch.float64
     assert float((XtZ - want).abs().max() / want.abs().max()) < (1e-9 if dt == torch.float64 else 1e-4)
+
+
+def test_several_cuda_devices_in_one_process_warn_and_point_to_torchrun():
+    """The reference's in-process multi-GPU call is not silently accepted: it warns (what it costs, how to
+    launch one rank per GPU instead) before anything is moved to a device."""
+    import warnings
+
+    from rlaopt_amd.kernels import DistributedRBFLinOp, KernelConfig
+
+    X = torch.randn(50, 3, dtype=torch.float64)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        try:
+            DistributedRBFLinOp(X, X, KernelConfig(lengthscale=1.0), devices={torch.device("cuda:0"), torch.device("cuda:1")})
+        except Exception:  # noqa: BLE001 - no GPU here: the construction itself cannot finish
+            pass
+    msgs = [str(w.message) for w in rec if issubclass(w.category, RuntimeWarning)]
+    assert any("one rank per GPU" in m and "torch.distributed.run" in m for m in msgs), msgs
