@@ -59,6 +59,8 @@ class SAP:
         power_iters=10,
         device="cpu",
         blk_sequence=None,
+        omega_sequence=None,
+        start_sequence=None,
     ):
         self.n, self.row_oracle, self.blk_oracle = n, row_oracle, blk_oracle
         self.B, self.reg = B, reg
@@ -67,6 +69,10 @@ class SAP:
         self.accel, self.power_iters, self.device = accel, power_iters, device
         self.probs = torch.ones(n) / n  # sap.py:54
         self._blk_iter = iter(blk_sequence) if blk_sequence is not None else None
+        # (pre-drawn test matrices / power-iteration starts: parity runs that share every draw with the
+        # product; None = drawn here with the reference's own torch calls)
+        self._omega_iter = iter(omega_sequence) if omega_sequence is not None else None
+        self._start_iter = iter(start_sequence) if start_sequence is not None else None
         if accel:  # sap.py:58-64
             self.beta = 1 - (mu / nu) ** 0.5
             self.gamma = 1 / (mu * nu) ** 0.5
@@ -101,7 +107,10 @@ class SAP:
 
             return pinv, rho == self.reg
         _, rank, rho, sketch, adaptive = self.precond
-        Om = _sk.get_sketch_matrix(sketch, "right", rank, self.blk_sz, self.B.dtype, self.device)
+        if self._omega_iter is not None:
+            Om = next(self._omega_iter)
+        else:
+            Om = _sk.get_sketch_matrix(sketch, "right", rank, self.blk_sz, self.B.dtype, self.device)
         st = _nys.build(Kbb, Om, rho)
         _nys.update_damping(st, self.reg, adaptive)
         return (lambda x: _nys.inverse_matmul(st, x)), False
@@ -116,6 +125,7 @@ class SAP:
             self.blk_sz,
             self.device,
             max_iters=self.power_iters,
+            v0=next(self._start_iter) if self._start_iter is not None else None,
         )
         return sig ** (-1.0)
 

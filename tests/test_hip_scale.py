@@ -397,3 +397,65 @@ def test_benchmark_regime_float64_iteration_on_float32_storage_converges(monkeyp
     torch.testing.assert_close(rel[head], want[head], rtol=2e-2, atol=0)
     ratio = rel[~head] / want[~head]
     assert float(ratio.max()) < 2.0 and float(ratio.min()) > 0.5, ratio
+
+
+# ---- ASkotch (BASELINE config 5) at mid size: 300 steps against the oracle with every draw shared --------
+@pytest.mark.parametrize("accel", [True, False])
+def test_midsize_askotch_300_steps_match_oracle(accel):
+    """n = 20 000, d = 50, k = 3, block n / 100 = 200, Nystrom rank 20, float32 - the shape ratios of BASELINE
+    config 5 (experiments/distributed_krr_linsys_askotch_solve_test.py:15-19,45-55) - for the configuration's
+    own 300 iterations.  Blocks, test matrices and power-iteration starts are drawn once and fed to both
+    sides; the oracle (oracle/sap.py = rlaopt/solvers/sap.py:25-175) runs on the dense float32 kernel matrix.
+    Asserted: the logged history (every 50 iterations) to 2e-3 relative and the final iterate to 2e-3 of its
+    norm.  Whether the residual falls is a property of the algorithm at this block size, not of the port: the
+    test records the trajectory of both sides."""
+    from oracle import krr
+    from oracle import sap as osap
+    from rlaopt_amd.kernels import DistributedRBFLinOp
+    from rlaopt_amd.solvers import SAPAccelConfig, SAPConfig
+    import rlaopt_amd.models.linsys as ml
+
+    n, d, k, blk_sz, rank, steps = 20000, 50, 3, 200, 20, 300
+    dt = torch.float32
+    g = torch.Generator().manual_seed(5)
+    X = (torch.randn(n, d, dtype=torch.float64, generator=g) / d**0.5).to(dt)
+    B = torch.randn(n, k, dtype=torch.float64, generator=g).to(dt)
+    reg, nu = 1e-2, 100.0
+    blocks = [torch.randperm(n, generator=g)[:blk_sz] for _ in range(steps)]
+    omegas = [(torch.randn(rank, blk_sz, dtype=torch.float64, generator=g) / rank**0.5).T.contiguous().to(dt)
+              for _ in range(steps)]
+    starts = [torch.randn(blk_sz, generator=g) for _ in range(steps)]
+    # oracle
+    Kop = krr.KernelOperator("rbf", X, 1.0, dense=True)
+    K = Kop.K
+    ref = osap.SAP(n, lambda blk: K[blk], lambda blk: K[blk][:, blk], B, reg, torch.zeros_like(B),
+                   ("nystrom", rank, reg, "gauss", True), blk_sz, accel=accel, mu=reg, nu=nu,
+                   blk_sequence=blocks, omega_sequence=omegas, start_sequence=starts)
+    Wref, logref = ol.run(ref, lambda V: K @ V, B, reg, steps, 0.0, 1e-12, callback_freq=50)
+    # product
+    Xd = X.to(DEV)
+    A = DistributedRBFLinOp(Xd, Xd, KernelConfig(lengthscale=1.0), devices={DEV})
+    system = LinSys(A, B.to(DEV), reg=reg, A_row_oracle=A.row_oracle, A_blk_oracle=A.blk_oracle)
+    cfg = SAPConfig(device=DEV, max_iters=steps, atol=0.0, rtol=1e-12,
+                    precond_config=NystromConfig(rank=rank, rho=reg, sketch="gauss"), blk_sz=blk_sz, accel=accel,
+                    accel_config=SAPAccelConfig(mu=reg, nu=nu) if accel else None)
+    orig = ml._get_solver
+
+    def patched(model, W_init, solver_config):
+        s = orig(model=model, W_init=W_init, solver_config=solver_config)
+        s.inject_draws(blocks=[b.to(DEV) for b in blocks], starts=[v.to(DEV) for v in starts])
+        return s
+
+    ml._get_solver = patched
+    try:
+        with sketches.inject(*omegas):
+            W, log = system.solve(cfg, torch.zeros(n, k, dtype=dt, device=DEV), callback_freq=50)
+    finally:
+        ml._get_solver = orig
+    assert sorted(log) == sorted(logref) == list(range(0, steps + 1, 50))
+    rel = torch.stack([log[i]["metrics"]["internal_metrics"]["rel_res"].cpu() for i in sorted(log)])
+    want = torch.stack([logref[i]["rel_res"] for i in sorted(logref)])
+    print(f"\n[askotch n={n} blk={blk_sz} r={rank} accel={accel}] rel_res (column 0) every 50 steps: "
+          f"{[round(float(v), 5) for v in rel[:, 0]]}; oracle: {[round(float(v), 5) for v in want[:, 0]]}")
+    torch.testing.assert_close(rel, want, rtol=2e-3, atol=0)
+    assert float((W.cpu() - Wref).norm() / Wref.norm()) < 2e-3

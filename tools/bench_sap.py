@@ -25,6 +25,11 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--rank", type=int, default=100)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--solve", action="store_true",
+                    help="the configuration end to end: LinSys.solve for max_iters = 300, callback_freq = 100 "
+                         "(experiments/distributed_krr_linsys_askotch_solve_test.py:45-75) - residual trajectory")
+    ap.add_argument("--max-iters", type=int, default=300)
+    ap.add_argument("--callback-freq", type=int, default=100)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     n, d, k = args.n, args.d, args.k
@@ -38,6 +43,23 @@ def main():
     cfg = SAPConfig(device=dev, max_iters=300, atol=1e-6, rtol=1e-6,
                     precond_config=NystromConfig(rank=args.rank, rho=reg), blk_sz=n // 100,
                     accel_config=SAPAccelConfig(mu=reg, nu=100.0))
+    if args.solve:
+        cfg.max_iters = args.max_iters
+        torch.manual_seed(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        W, log = system.solve(cfg, torch.zeros(n, k, device=dev), callback_freq=args.callback_freq)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        its = sorted(log)
+        traj = {i: [round(float(v), 5) for v in log[i]["metrics"]["internal_metrics"]["rel_res"]] for i in its}
+        solver_s = log[its[-1]]["cum_time"]
+        print(json.dumps({"workload": f"askotch solve n={n} d={d} k={k} blk={cfg.blk_sz} rank={args.rank} f32 "
+                                      f"mu={reg} nu=100 max_iters={args.max_iters} callback_freq={args.callback_freq}",
+                          "iters": its[-1], "wall_s": round(wall, 3), "solver_s_excluding_metrics": round(solver_s, 3),
+                          "ms_per_iter": round(1e3 * solver_s / max(its[-1], 1), 3),
+                          "rel_res_by_iteration": traj}))
+        return
     torch.manual_seed(0)
     solver = SAP(system, torch.zeros(n, k, device=dev), cfg.precond_config, dev, cfg.blk_sz, True,
                  cfg.accel_config, cfg.power_iters)
