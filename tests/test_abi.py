@@ -73,3 +73,50 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def integration_stub_source():
+    """The reference-side binding of INTEGRATION.md section B, verbatim (the fenced block that defines
+    ``kernel_matmat``)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stubs = [b for b in blocks if "def kernel_matmat(" in b]
+    assert len(stubs) == 1
+    return stubs[0]
+
+
+def load_integration_stub():
+    """Execute the stub as a maintainer would have it in rlaopt/kernels/_rk.py; only the library lookup is
+    redirected to the in-tree build (the stub names the bare soname)."""
+    from rlaopt_amd import _lib
+
+    class _Ctypes:  # ctypes with CDLL("librk_hip.so") resolved to the in-tree file
+        def __getattr__(self, name):
+            return getattr(ctypes, name)
+
+        @staticmethod
+        def CDLL(name, *a, **k):
+            return ctypes.CDLL(_lib.LIB_PATH if name == "librk_hip.so" else name, *a, **k)
+
+    src = integration_stub_source()
+    assert src.startswith("import ctypes, torch\n")
+    ns = {"ctypes": _Ctypes()}
+    exec(compile(src.replace("import ctypes, torch\n", "import torch\n", 1), "INTEGRATION.md::_rk.py", "exec"), ns)
+    return ns
+
+
+def test_integration_stub_signature_matches_the_binding():
+    """The ctypes stub a maintainer would paste into the reference declares rk_kernel_matmat exactly as the
+    package's own binding does (it cannot drift from the ABI silently)."""
+    from rlaopt_amd import _lib
+
+    ns = load_integration_stub()
+    lib = ns["_lib"]
+    restype, argtypes = _lib.SIGNATURES["rk_kernel_matmat"]
+    assert lib.rk_kernel_matmat.restype is restype
+    assert list(lib.rk_kernel_matmat.argtypes) == list(argtypes)
+    restype, argtypes = _lib.SIGNATURES["rk_kernel_matmat_ws_bytes"]
+    assert lib.rk_kernel_matmat_ws_bytes.restype is restype
+    assert list(lib.rk_kernel_matmat_ws_bytes.argtypes) == list(argtypes)
+    assert ns["_KIND"] == {"RBF": 0, "Laplace": 1, "Matern12": 2, "Matern32": 3, "Matern52": 4}
+    assert {k: v for k, v in _lib.KIND_IDS.items()} == {"rbf": 0, "laplace": 1, "matern12": 2, "matern32": 3, "matern52": 4}

@@ -845,3 +845,50 @@ def test_symm_gemm_wide_product_from_the_packed_strips(be, monkeypatch, n, k, fi
         got2 = be.symm_gemm(Kp, n, wide[:, 2 : 2 + k], kmax=scale, alpha=-0.5).cpu().double()
         want2 = -0.5 * (Kd @ wide[:, 2 : 2 + k].cpu().double())
         assert float((got2 - want2).norm() / want2.norm()) < 5e-6
+
+
+@pytest.mark.parametrize("name,kind", [("RBF", "rbf"), ("Laplace", "laplace"), ("Matern12", "matern12"),
+                                       ("Matern32", "matern32"), ("Matern52", "matern52")])
+def test_integration_md_stub_runs_against_the_oracle(be, prec, name, kind):
+    """INTEGRATION.md section B, executed verbatim: the ctypes stub a maintainer would add to the reference
+    (rlaopt/kernels/_rk.py) drives librk_hip.so directly - plain products, 1-D x, row and block oracles with
+    in-kernel index gathers, per-feature (ARD) lengthscales, const_scaling, the matrix-core opt-in - and
+    agrees with the oracle at the reference's tolerances."""
+    from test_abi import load_integration_stub
+
+    km = load_integration_stub()["kernel_matmat"]
+    dt = DTYPES[prec]
+    g = torch.Generator().manual_seed(11)
+    n1, n2, d, k = 333, 1201, 7, 5
+    A1 = (torch.randn(n1, d, dtype=dt, generator=g) / d**0.5).to(dev())
+    A2 = (torch.randn(n2, d, dtype=dt, generator=g) / d**0.5).to(dev())
+    x = torch.randn(n2, k, dtype=dt, generator=g).to(dev())
+    ard = (torch.rand(d, dtype=dt, generator=g) + 0.5).to(dev())
+    lim = LIM[dt] * 5
+    for ell in (0.8, ard):
+        want = ok.kernel_matmat(kind, A1.cpu().double(), A2.cpu().double(), ell.cpu().double() if isinstance(ell, torch.Tensor) else ell,
+                                x.cpu().double(), 1.7)
+        assert rel_err(km(name, A1, A2, ell, 1.7, x).cpu(), want) < lim
+        assert rel_err(km(name, A1, A2, ell, 1.7, x[:, 0].contiguous()).cpu(), want[:, 0]) < lim
+    # row oracle K(A1[blk], A2) and block oracle K(A2[blk], A2[blk]): device int64 index lists
+    blk = torch.randperm(n1, generator=g)[:50].to(dev())
+    want = ok.kernel_matmat(kind, A1.cpu().double(), A2.cpu().double(), 1.0, x.cpu().double(), 1.0, idx1=blk.cpu())
+    assert rel_err(km(name, A1, A2, 1.0, 1.0, x, idx1=blk).cpu(), want) < lim
+    blk2 = torch.randperm(n2, generator=g)[:64].to(dev())
+    w = torch.randn(64, 2, dtype=dt, generator=g).to(dev())
+    want = ok.kernel_matmat(kind, A2.cpu().double(), A2.cpu().double(), ard.cpu().double(), w.cpu().double(), 1.0,
+                            idx1=blk2.cpu(), idx2=blk2.cpu())
+    assert rel_err(km(name, A2, A2, ard, 1.0, w, idx1=blk2, idx2=blk2).cpu(), want) < lim
+    # the transpose product of the table: K(A1, A2)^T u = K(A2, A1) u
+    u = torch.randn(n1, 3, dtype=dt, generator=g).to(dev())
+    want = ok.kernel_rmatmat(kind, A1.cpu().double(), A2.cpu().double(), 1.0, u.cpu().double(), 1.0)
+    assert rel_err(km(name, A2, A1, 1.0, 1.0, u).cpu(), want) < lim
+    # opting in to the matrix-core formulation with the operator's centre (float32, smooth kernels)
+    if dt == torch.float32 and kind in ("rbf", "matern32", "matern52"):
+        gc = be.gram_center(A1, A2, 1.0)
+        assert gc is not None
+        want = ok.kernel_matmat(kind, A1.cpu().double(), A2.cpu().double(), 1.0, x.cpu().double(), 1.0)
+        assert rel_err(km(name, A1, A2, 1.0, 1.0, x, gram_center=gc).cpu(), want) < lim
+    # errors surface as the exceptions the stub documents
+    with pytest.raises(ValueError):  # more than 16 columns per call: rejected by the C side, status -1
+        km(name, A1, A2, 1.0, 1.0, torch.zeros(n2, 17, dtype=dt, device=dev()))

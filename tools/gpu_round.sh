@@ -29,4 +29,15 @@ timeout -k 10 300 python3 tools/bench_skinny.py > $OUT/${TAG}_bench_skinny.log 2
 timeout -k 10 200 python3 tools/bench_dense_c1.py > $OUT/${TAG}_bench_dense_c1.log 2>&1 && echo "dense c1 ok" && tail -1 $OUT/${TAG}_bench_dense_c1.log | cut -c1-200
 # storage-free PCG (matrix-free operator, symmetric evaluation)
 RK_KERNEL_MODE=matrix_free timeout -k 10 300 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-solve > $OUT/${TAG}_bench_matrix_free.log 2>&1 && echo "matrix-free pcg ok"
+# BASELINE config 2 (n = 50 000, d = 32, r = 512 float32) as a bench line of its own
+timeout -k 10 300 python3 bench.py --n 50000 --d 32 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/${TAG}_bench_c2.log 2>&1 && echo "c2 ok" && tail -1 $OUT/${TAG}_bench_c2.log | cut -c1-200
+# the sketch product from the packed strips (rk_symm_gemm): timing, error, SQ counters; the Nystrom assembly by stage
+timeout -k 10 300 python3 tools/bench_symgemm.py --fold 16 > $OUT/${TAG}_bench_symgemm.log 2>&1 && echo "symgemm ok"
+timeout -k 10 300 python3 tools/profile_nystrom_setup.py > $OUT/${TAG}_nystrom_setup.log 2>&1 && echo "nystrom setup ok"
+bash tools/pmc_symgemm.sh ${TAG} > $OUT/${TAG}_pmc_symgemm.log 2>&1 && python3 tools/pmc_table.py $OUT/${TAG}_sq symgemm_kernel > $OUT/${TAG}_symgemm_sq_counters.txt && echo "pmc symgemm ok"
+# ASkotch end to end (300 iterations, callback_freq 100): residual trajectory
+timeout -k 10 300 python3 tools/bench_sap.py --solve > $OUT/${TAG}_sap_solve.log 2>&1 && echo "sap solve ok" && tail -1 $OUT/${TAG}_sap_solve.log | cut -c1-300
+# rehearsal of the multi-rank path: two gloo ranks sharing this one GPU (n = 100 000)
+RK_BENCH_BACKEND=gloo RK_BENCH_ONE_GPU=1 RK_BENCH_N=100000 timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 20 --warmup 5 --no-solve > $OUT/${TAG}_bench_gloo_world2.log 2>&1 && echo "gloo world 2 ok"
+timeout -k 10 120 python3 tools/host_probe.py > $OUT/${TAG}_host_probe.log 2>&1 && echo "host probe ok"
 ls -R $OUT | grep -c csv

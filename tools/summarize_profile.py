@@ -25,6 +25,21 @@ shutil.copy(f"{src}/{tag}_bench_n1.log", f"{dst}/{tag}_bench_n1.log")
 rows = list(csv.DictReader(open(stats)))
 
 
+def medians(trace_path):
+    """Median / min duration (us) per kernel name from a --kernel-trace CSV: a process's first launch of a
+    kernel includes its code-object load (one 199 ms first launch made a 2.2 ms kernel average 12 ms in the
+    round-2 ASkotch table) - the median is what a steady-state launch costs."""
+    per = {}
+    if os.path.exists(trace_path):
+        for r in csv.DictReader(open(trace_path)):
+            per.setdefault(r["Kernel_Name"], []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    out = {}
+    for name, v in per.items():
+        v.sort()
+        out[name] = (v[len(v) // 2], v[0])
+    return out
+
+
 bench = json.loads([l for l in open(f"{src}/{tag}_bench_n1.log") if l.startswith("{")][-1])
 storage = bench["roofline"].get("storage", "materialize")
 KNAME = "symm_strip_kernel<float, float, 1>" if storage.startswith("sympack") else "skinny_nn_kernel<float, 1, 8"
@@ -63,9 +78,11 @@ with open(f"{dst}/{tag}_summary.md", "w") as f:
             f"({100 * bench['roofline']['frac']:.1f} % of 8000), avg launch "
             f"{bench['roofline']['avg_launch_ms']:.3f} ms (HIP events in bench.py)\n\n")
     f.write("## kernel stats (rocprofv3 --kernel-trace --stats, whole process incl. setup)\n\n")
-    f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+    f.write("| kernel | calls | total ms | median us | min us | avg us | % |\n|---|---|---|---|---|---|---|\n")
+    med = medians(f"{src}/{tag}_prof/{tag}_kernel_trace.csv")
     for r in rows[:16]:
-        f.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | "
+        md, mn = med.get(r["Name"], (float("nan"), float("nan")))
+        f.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {md:.1f} | {mn:.1f} | "
                 f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
     f.write(f"\nDominant kernel: `{KNAME}` (storage mode {storage}). Its shard-product launches alone "
             f"(kernel-trace rows of that kernel, long ones only): **{len(shard)} launches, "
@@ -113,9 +130,11 @@ with open(f"{dst}/{tag}_summary.md", "w") as f:
         shutil.copy(st, f"{dst}/{tag}_{name}_kernel_stats.csv")
         line = [l for l in open(blog) if l.startswith("{")][-1].strip()
         f.write(f"## {title}\n\nun-profiled run: `{line[:700]}`\n\n")
-        f.write("| kernel (rocprofv3 --stats of the same script) | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+        f.write("| kernel (rocprofv3 --kernel-trace --stats of the same script) | calls | total ms | median us | min us | avg us | % |\n|---|---|---|---|---|---|---|\n")
+        med2 = medians(f"{src}/{tag}_prof_{name}/{tag}_{name}_kernel_trace.csv")
         for r in list(csv.DictReader(open(st)))[:8]:
-            f.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | "
+            md, mn = med2.get(r["Name"], (float("nan"), float("nan")))
+            f.write(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {md:.1f} | {mn:.1f} | "
                     f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
         f.write("\n")
     # matrix-free kernel product (rk_kernel_matmat): formulations side by side + matrix-core counter
@@ -160,6 +179,24 @@ with open(f"{dst}/{tag}_summary.md", "w") as f:
         for l in open(blog):
             if l.startswith("{"):
                 f.write(l[:420].rstrip() + "\n")
+        f.write("```\n\n")
+    for name, title in (("bench_c2", "BASELINE config 2: bench.py --n 50000 --d 32 --steps 200"),
+                        ("bench_symgemm", "Sketch product Y = K Omega from the packed strips (tools/bench_symgemm.py)"),
+                        ("nystrom_setup", "Nystrom assembly by stage (tools/profile_nystrom_setup.py)"),
+                        ("symgemm_sq_counters", "SQ counters of the sketch kernel (tools/pmc_symgemm.sh)"),
+                        ("sap_solve", "ASkotch end to end: tools/bench_sap.py --solve (300 iterations, callback_freq 100)"),
+                        ("bench_gloo_world2", "Two gloo ranks on one GPU: the multi-rank path of bench.py (n = 100 000)"),
+                        ("host_probe", "Host of the box (tools/host_probe.py)")):
+        ext = "txt" if name.endswith("counters") else "log"
+        blog = f"{src}/{tag}_{name}.{ext}"
+        if not os.path.exists(blog):
+            continue
+        shutil.copy(blog, f"{dst}/{tag}_{name}.{ext}")
+        f.write(f"## {title}\n\n```\n")
+        for l in open(blog):
+            if l.startswith(("[W", "[Gloo", "/opt/amdgpu", "W1", "*****")) or not l.strip():
+                continue
+            f.write(l[:600].rstrip() + "\n")
         f.write("```\n\n")
     f.write("## HBM traffic of the shard product (separate --pmc passes)\n\n")
     f.write(f"FETCH_SIZE = {fetch:.0f} KB, WRITE_SIZE = {write:.0f} KB per launch -> "
