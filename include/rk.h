@@ -164,6 +164,16 @@ int rk_symm_matmat(int dtype, int store_dtype, const void* Kp, int64_t n, int64_
                    double diag_shift, void* Y, int64_t ldy, void* ws, size_t ws_bytes,
                    void* stream);
 
+/* The same product for 1 <= k <= 16 right-hand sides (float32 storage and vectors) on the 16-BIT matrix cores:
+ * stored entries and V are split into two float16 pieces each (three exact products per pair, float32
+ * accumulation; entry error <= 2.4e-7 relative), both uses of a stored tile out of one LDS image (row reads and
+ * transposing reads).  kmax: an upper bound on the magnitude of the stored entries (the operator's
+ * const_scaling).  Replaces rk_symm_matmat for 4 <= k <= 16 (rlaopt/solvers/pcg.py:58 with several columns). */
+size_t rk_symm_matmat_f16x2_ws_bytes(int64_t n, int64_t k, int64_t strip_first, int64_t strip_stride);
+int rk_symm_matmat_f16x2(const void* Kp, int64_t n, int64_t strip_first, int64_t strip_stride, double kmax,
+                         const void* V, int64_t k, int64_t ldv, double alpha, double diag_shift, void* Y,
+                         int64_t ldy, void* ws, size_t ws_bytes, void* stream);
+
 /* Wide product with the packed matrix: Y (n x k) = alpha * (this rank's partial of) K V for 17 <= k <= 1024
  * columns - the Nystrom sketch product Y = K Omega (rlaopt/preconditioners/nystrom.py:79-80, the one
  * n x n x r product of a solve; the reference sends Omega through its worker queues,

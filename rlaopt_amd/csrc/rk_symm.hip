@@ -525,7 +525,8 @@ template <typename T>
 __global__ void __launch_bounds__(1024)
 symm_finish_kernel(SymLayout L, int K, int KT, const T* __restrict__ Prow, const T* __restrict__ Pcol,
                    int64_t max_items, T alpha, T shift, const T* __restrict__ V, int64_t ldv,
-                   T* __restrict__ Y, int64_t ldy) {  // KT: entries per table row (>= K)
+                   T* __restrict__ Y, int64_t ldy,
+                   const float* __restrict__ colscale = nullptr) {  // KT: entries per table row (>= K)
     constexpr int NS = 16;
     __shared__ T red[NS][64];
     const int W = L.W;
@@ -569,8 +570,305 @@ symm_finish_kernel(SymLayout L, int K, int KT, const T* __restrict__ Prow, const
 #pragma unroll
         for (int y = 0; y < NS; ++y) sum += red[y][tx];
         T y = alpha * sum;
+        if (colscale != nullptr) y *= (T)colscale[c];  // (tables of the float16-split kernel hold scaled sums)
         if (shift != T(0)) y += shift * V[i * ldv + c];
         Y[i * ldy + c] = y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// the strip product for up to 16 right-hand sides on the 16-BIT matrix cores (float32 storage and vectors)
+// ------------------------------------------------------------------------------------------
+// symm_strip_mfma_kernel above is bound by the float32 matrix cores: 64 v_mfma_f32_16x16x4_f32 (32 cycles
+// each) per wave and 32 KiB tile = 2 048 cycles, 54 % busy at 4.3 - 4.6 TB/s.  Here every stored entry and
+// every entry of V is split into two float16 pieces (x 2^e = h + m + O(2^-22 |x|), see rk_symgemm.hip) and
+// both uses of a tile run as three exact v_mfma_f32_16x16x32_f16 products (h.h + h.m + m.h): 24 MFMAs of
+// 16 cycles per wave and tile = 384 cycles.
+//   * staging: a wave loads whole stored rows (lane <-> 4 consecutive columns), scales, splits and writes
+//     8 bytes per piece into two row-major float16 images [32 rows][256 columns];
+//   * row part  Yrow[32 x 16] = T[32 x 256] V[256 x 16]: contraction along a stored row - the A operand
+//     (row = lane % 16, 8 consecutive columns) is one ds_read_b128 of the row-major image; B = the strip's
+//     V columns, pre-split rhs-major (16 bytes = 8 consecutive j of one right-hand side), in registers for
+//     the whole item;
+//   * column part  Ycol[256 x 16] += T^T[256 x 32] V_i[32 x 16]: contraction DOWN the tile's 32 rows - the
+//     A operand (column = lane % 16, 8 consecutive rows) comes out of the SAME image through the transposing
+//     LDS read ds_read_b64_tr_b16 (two per operand: lane 4q + p of a 16-lane group addresses row q, columns
+//     4p .. 4p + 3 and lane i receives column i of the four rows); B = V of the tile's rows, a 16-byte global
+//     load per piece and tile.  Row stride 544 bytes + an XOR of the 32-byte column blocks (h2_off): both read
+//     patterns and the 8-byte writes are bank-conflict free.
+// Accumulation: the row part's chains are 12 MFMAs long (then float32 adds); the column part's accumulators
+// are folded into a second set every 8 tiles (the matrix cores' float32 accumulation truncates, ~1e-8 per
+// step of a chain).  Tables, work items and the finishing kernel are those of the kernels above; the
+// per-column unscaling rides in the finishing kernel.
+constexpr int H2_TR = 32;                 // rows per tile
+constexpr int H2_ROWB = 544;              // bytes of one image row (256 halves + 32 bytes of padding)
+// byte offset of 16-column block c16 (0 .. 15) of image row `row`: the blocks of rows with bit 2 != bit 3 are
+// XOR-ed with 4 (found by exhaustive search over strides and XOR masks: with it the operand fetch of the row part
+// (ds_read_b128, 16 rows x 4 chunks per lane group), the transposed fetch of the column part (ds_read_b64_tr_b16, rows
+// q and 8 + q in one 32-lane half) and the 8-byte stores are ALL bank-conflict free)
+__host__ __device__ __forceinline__ int h2_off(int row, int c16) {
+    return row * H2_ROWB + ((c16 ^ (4 * (((row >> 3) ^ (row >> 2)) & 1))) << 5);
+}
+constexpr int H2_PIECE = H2_TR * H2_ROWB;  // one piece of one tile: 16 896 bytes
+constexpr int H2_FOLD = 8;                // tiles between folds of the column accumulators
+typedef unsigned int h2_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int h2_u2 __attribute__((ext_vector_type(2)));
+typedef float h2_acc __attribute__((ext_vector_type(4)));
+typedef _Float16 h2_h8 __attribute__((ext_vector_type(8)));
+typedef short h2_s4 __attribute__((ext_vector_type(4)));
+constexpr size_t h2_smem_bytes() {  // 2 buffers x 2 pieces + row parts of the 2 column halves (2 buffers)
+    return (size_t)(2 * 2 * H2_PIECE) + (size_t)(2 * 2 * H2_TR * SMK) * sizeof(float);
+}
+
+__device__ __forceinline__ void h2_split2(float a, float b, unsigned& h, unsigned& m) {
+    const _Float16 ha = (_Float16)a, hb = (_Float16)b;   // round to nearest even
+    const float ra = a - (float)ha, rb = b - (float)hb;  // exact
+    const _Float16 ma = (_Float16)ra, mb = (_Float16)rb;
+    h = (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+    m = (unsigned)__builtin_bit_cast(unsigned short, ma) | ((unsigned)__builtin_bit_cast(unsigned short, mb) << 16);
+}
+__device__ __forceinline__ h2_acc h2_mfma(h2_u4 a, h2_u4 b, h2_acc c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h2_h8, a), __builtin_bit_cast(h2_h8, b), c, 0, 0, 0);
+}
+// h.h + h.m + m.h, small terms first
+__device__ __forceinline__ h2_acc h2_mfma3(const h2_u4 (&a)[2], const h2_u4 (&b)[2], h2_acc c) {
+    c = h2_mfma(a[1], b[0], c);
+    c = h2_mfma(a[0], b[1], c);
+    return h2_mfma(a[0], b[0], c);
+}
+
+// largest |V[:, c]| per column (float bits; non-negative floats order like integers)
+__global__ void __launch_bounds__(256)
+h2_absmax_kernel(const float* __restrict__ V, int64_t n, int k, int64_t ldv, unsigned* __restrict__ out) {
+    const int c = threadIdx.x & 15;
+    if (c >= k) return;
+    float m = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); r < n; r += (int64_t)gridDim.x * 16) {
+        const float v = fabsf(V[r * ldv + c]);
+        m = (v == v && v > m) ? v : m;
+    }
+    if (m > 0.f) atomicMax(out + c, __float_as_uint(m));
+}
+// info[16 + c] <- 2^eb(c) (V is scaled by it), info[32 + c] <- 2^-(ea + eb(c)) (the unscaling)
+__global__ void h2_scale_kernel(unsigned* __restrict__ info, int ea) {
+    const int c = threadIdx.x;
+    if (c >= SMK) return;
+    int eb = 0;
+    const float m = __uint_as_float(info[c]);
+    if (m > 0.f && m < 3.0e38f) {
+        int ex;
+        frexpf(m, &ex);
+        eb = 14 - ex;
+        eb = eb > 100 ? 100 : (eb < -100 ? -100 : eb);
+    }
+    info[16 + c] = __float_as_uint(ldexpf(1.f, eb));
+    info[32 + c] = __float_as_uint(ldexpf(1.f, -eb) * ldexpf(1.f, -ea));
+}
+// Vt[piece][rhs (16)][j (npad)] float16: one thread per (rhs, 8-row chunk); rows >= n and rhs >= k are zero
+__global__ void __launch_bounds__(256)
+h2_split_v_kernel(const float* __restrict__ V, int64_t n, int64_t npad, int k, int64_t ldv,
+                  const unsigned* __restrict__ info, unsigned short* __restrict__ Vt) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(g & 15);
+    const int64_t chunk = g >> 4;
+    if (chunk >= npad / 8) return;
+    const float sb = __uint_as_float(info[16 + c]);
+    unsigned h[4], m[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int64_t j = chunk * 8 + 2 * e;
+        const float a = (j < n && c < k) ? V[j * ldv + c] * sb : 0.f;
+        const float b = (j + 1 < n && c < k) ? V[(j + 1) * ldv + c] * sb : 0.f;
+        h2_split2(a, b, h[e], m[e]);
+    }
+    h2_u4 oh, om;
+    oh.x = h[0]; oh.y = h[1]; oh.z = h[2]; oh.w = h[3];
+    om.x = m[0]; om.y = m[1]; om.z = m[2]; om.w = m[3];
+    *reinterpret_cast<h2_u4*>(Vt + ((int64_t)c * npad + chunk * 8)) = oh;
+    *reinterpret_cast<h2_u4*>(Vt + ((int64_t)(SMK + c) * npad + chunk * 8)) = om;
+}
+
+// (A wave-private variant - each wave walks its own 16-row slabs, row-part operands straight from the load
+// registers, the column part through one ds_read_b64_tr_b16 per block and v_mfma_f32_16x16x16_f16, two barriers
+// per 1 MiB item instead of one per tile - was built and measured: 18.6 - 19.3 ms against 16.6 - 17.8 ms for the
+// tile-staged kernel below; its loads touch 16 rows x 64 bytes per instruction and stream at 4.3 TB/s.  What
+// bounds the tile-staged kernel is the traffic of the partial tables, not the matrix cores: see KTAB.)
+//
+// KTAB: the (strip, row) and (item, column) tables hold KTAB = k entries per row / column, not 16: at k = 5 that is
+// 3.9 GB of table traffic (written here, read by the finishing kernel) instead of 12.6 GB beside the 80 GB triangle.
+__global__ void __launch_bounds__(SYMM_THREADS, 2)
+symm_strip_h2_kernel(const float* __restrict__ Kp, SymLayout L, const unsigned short* __restrict__ Vt, int64_t npad,
+                     float sa, int ktab, float* __restrict__ Prow, float* __restrict__ Pcol, int64_t max_items,
+                     int64_t total_items) {
+    constexpr int W = 256;
+    constexpr int TR = H2_TR;
+    constexpr int RPW = TR / 4;  // staged rows per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
+    unsigned char* TB = sm_raw;                                               // [2 buffers][2 pieces][TR][544 B]
+    float* RP = reinterpret_cast<float*>(sm_raw + 2 * 2 * H2_PIECE);          // [2][2 halves][TR][SMK]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int rb = wave & 1, cs = wave >> 1;  // row part: 16 rows x 128 columns per wave
+    const unsigned short* Vh = Vt;                          // piece 0: [16][npad]
+    const unsigned short* Vm = Vt + (int64_t)SMK * npad;    // piece 1
+    // transposing read: lane 4q + p of a 16-lane group addresses (row q, columns 4p .. 4p + 3) of its block
+    const int trq = (lane >> 2) & 3, trp = lane & 3;
+    // (the XOR of h2_off moves whole groups of four blocks: block 4 wave + cb of rows 8 lq + q / + 4 sits at
+    // h2_off(row, 4 wave) + 32 cb)
+    const int tr_lo = h2_off(8 * lq + trq, 4 * wave) + 8 * trp;
+    const int tr_hi = h2_off(8 * lq + trq + 4, 4 * wave) + 8 * trp;
+    int aoff[4];  // row part: row 16 rb + lr, columns 128 cs + 32 s + 8 lq .. + 8
+#pragma unroll
+    for (int s = 0; s < 4; ++s) aoff[s] = h2_off(16 * rb + lr, 8 * cs + 2 * s + (lq >> 1)) + (lq & 1) * 16;
+    int64_t t = 0, before = 0;
+    for (int64_t id = blockIdx.x; id < total_items; id += gridDim.x) {
+        for (;;) {
+            const int64_t cnt = (L.rows(t) + ITEM_ROWS - 1) / ITEM_ROWS;
+            if (id < before + cnt) break;
+            before += cnt;
+            ++t;
+        }
+        const int64_t chunk = id - before;
+        const int64_t nrows = uniform64(L.rows(t));
+        const int64_t item_lo = uniform64(chunk * ITEM_ROWS);
+        const int64_t item_hi = item_lo + ITEM_ROWS < nrows ? item_lo + ITEM_ROWS : nrows;
+        const int64_t diag_lo = uniform64(L.strip(t) * W);
+        const float* base = Kp + uniform64(L.row_offset(t) * W);
+        const int ntile = (int)((item_hi - item_lo + TR - 1) / TR);
+
+        // B operands of the row part: V[j = diag_lo + 128 cs + 32 s + 8 lq .. + 8][rhs = lr], both pieces
+        h2_u4 vB[4][2];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int64_t j = diag_lo + 128 * cs + 32 * s + 8 * lq;  // < npad
+            vB[s][0] = *reinterpret_cast<const h2_u4*>(Vh + (int64_t)lr * npad + j);
+            vB[s][1] = *reinterpret_cast<const h2_u4*>(Vm + (int64_t)lr * npad + j);
+        }
+        h2_acc ccol[4], ctot[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { ccol[cb][v] = 0.f; ctot[cb][v] = 0.f; }
+
+        float4 preA[RPW], preB[RPW];
+        h2_u4 viA[2], viB[2];
+        auto load_tile = [&](int tl, float4 (&pre)[RPW], h2_u4 (&vi)[2]) {
+            const int64_t r0 = item_lo + (int64_t)(tl < ntile ? tl : ntile - 1) * TR;
+#pragma unroll
+            for (int u = 0; u < RPW; ++u) {
+                const int64_t i = r0 + wave + 4 * u;
+                pre[u] = load_stream_at<float4>(base + (i < nrows ? i : nrows - 1) * W, (unsigned)lane * 16u);
+            }
+            // V of the tile's rows (B operand of the column part): rows r0 + 8 lq .. + 8 of rhs lr (r0 + 32 <= npad)
+            vi[0] = *reinterpret_cast<const h2_u4*>(Vh + (int64_t)lr * npad + r0 + 8 * lq);
+            vi[1] = *reinterpret_cast<const h2_u4*>(Vm + (int64_t)lr * npad + r0 + 8 * lq);
+        };
+        auto store_tile = [&](int buf, int tl, const float4 (&pre)[RPW]) {
+            unsigned char* tb = TB + buf * 2 * H2_PIECE;
+            const int64_t r0 = item_lo + (int64_t)(tl < ntile ? tl : ntile - 1) * TR;
+#pragma unroll
+            for (int u = 0; u < RPW; ++u) {
+                const float m = r0 + wave + 4 * u < item_hi ? sa : 0.f;  // rows past the item: exact zeros
+                unsigned h0, h1, m0, m1;
+                h2_split2(pre[u].x * m, pre[u].y * m, h0, m0);
+                h2_split2(pre[u].z * m, pre[u].w * m, h1, m1);
+                h2_u2 h, mm;
+                h.x = h0; h.y = h1; mm.x = m0; mm.y = m1;
+                unsigned char* dst = tb + h2_off(wave + 4 * u, lane >> 2) + (lane & 3) * 8;
+                *reinterpret_cast<h2_u2*>(dst) = h;
+                *reinterpret_cast<h2_u2*>(dst + H2_PIECE) = mm;
+            }
+        };
+        auto flush_rows = [&](int buf, int tl) {  // add the two column halves, store to the row table
+            const float* rp = RP + buf * 2 * TR * SMK;
+            float* pr = Prow + (L.row_offset(t) + item_lo + (int64_t)tl * TR) * ktab;
+            const int64_t live = item_hi - item_lo - (int64_t)tl * TR;  // rows
+#pragma unroll
+            for (int e = tid; e < TR * SMK; e += SYMM_THREADS) {
+                const int r = e >> 4, c = e & 15;
+                const float sum = rp[e] + rp[TR * SMK + e];
+                if (r < live && c < ktab) __builtin_nontemporal_store(sum, &pr[r * ktab + c]);
+            }
+        };
+        auto compute = [&](int buf, int tl, const h2_u4 (&vi)[2]) {
+            if (tl > 0) flush_rows(buf ^ 1, tl - 1);  // (RP[buf ^ 1] was completed before the last barrier)
+            const unsigned char* tb = TB + buf * 2 * H2_PIECE;
+            // ---- row part: A = rows 16 rb + lr, columns 128 cs + 32 s + 8 lq .. + 8 -----------------------
+            h2_acc crow;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) crow[v] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                h2_u4 a[2];
+                a[0] = *reinterpret_cast<const h2_u4*>(tb + aoff[s]);
+                a[1] = *reinterpret_cast<const h2_u4*>(tb + aoff[s] + H2_PIECE);
+                crow = h2_mfma3(a, vB[s], crow);
+            }
+            float* rp = RP + (buf * 2 + cs) * TR * SMK;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) rp[(16 * rb + 4 * lq + v) * SMK + lr] = crow[v];
+            // ---- column part (rows above the diagonal block only; tile-uniform): A = T^T through the
+            // transposing read: columns 64 wave + 16 cb + (0 .. 15), rows 8 lq .. 8 lq + 7 ---------------------
+            if (item_lo + (int64_t)tl * TR < diag_lo) {
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    h2_u4 a[2];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        typedef __attribute__((address_space(3))) h2_s4* lds_s4;
+                        const unsigned char* src = tb + cb * 32 + p * H2_PIECE;
+                        const h2_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(src + tr_lo));
+                        const h2_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(src + tr_hi));
+                        const h2_u2 l2 = __builtin_bit_cast(h2_u2, lo), h2v = __builtin_bit_cast(h2_u2, hi);
+                        a[p].x = l2.x; a[p].y = l2.y; a[p].z = h2v.x; a[p].w = h2v.y;
+                    }
+                    ccol[cb] = h2_mfma3(a, vi, ccol[cb]);
+                }
+                if ((tl & (H2_FOLD - 1)) == H2_FOLD - 1) {
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) {
+                        ctot[cb] += ccol[cb];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) ccol[cb][v] = 0.f;
+                    }
+                }
+            }
+        };
+
+        load_tile(0, preA, viA);
+        store_tile(0, 0, preA);
+        h2_u4 vi0[2] = {viA[0], viA[1]};  // V rows of the tile being computed travel one stage behind the loads
+        load_tile(1, preA, viA);
+        load_tile(2, preB, viB);
+        __syncthreads();
+        for (int tl = 0; tl < ntile; tl += 2) {
+            store_tile(1, tl + 1, preA);
+            h2_u4 vi1[2] = {viA[0], viA[1]};
+            load_tile(tl + 3, preA, viA);
+            compute(0, tl, vi0);
+            __syncthreads();  // tile tl + 1 staged, RP[0] complete, everyone done with TB[0]
+            if (tl + 1 < ntile) {
+                store_tile(0, tl + 2, preB);
+                vi0[0] = viB[0]; vi0[1] = viB[1];
+                load_tile(tl + 4, preB, viB);
+                compute(1, tl + 1, vi1);
+                __syncthreads();
+            }
+        }
+        flush_rows((ntile - 1) & 1, ntile - 1);
+        // column sums of the item: element v of ccol[cb] = Ycol[column 64 wave + 16 cb + 4 lq + v][rhs = lr]
+        float* pc = Pcol + ((t * max_items + chunk) * W) * ktab;
+        if (lr < ktab) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    __builtin_nontemporal_store(ctot[cb][v] + ccol[cb][v],
+                                                &pc[(64 * wave + 16 * cb + 4 * lq + v) * ktab + lr]);
+        }
+        __syncthreads();  // RP / TB are reused by the next item
     }
 }
 
@@ -753,6 +1051,73 @@ static int symm_matmat_wide_impl(const T* Kp, int64_t n, int64_t first, int64_t 
     return launch_status("rk_symm_matmat(finish)");
 }
 
+// ---- up to 16 right-hand sides on the 16-bit matrix cores (float32) -------------------------------------------
+static size_t symm_h2_ws_bytes(int64_t n, int64_t first, int64_t stride) {
+    const SymLayout L = make_layout<float>(n, first, stride);
+    const int64_t max_items = ceil_div(n, ITEM_ROWS);
+    const size_t npad = (size_t)round_up(n, 256);
+    const size_t vt = 2 * SMK * npad * sizeof(unsigned short);            // both pieces, rhs-major
+    const size_t prow = (size_t)L.total_rows() * SMK * sizeof(float);
+    const size_t pcol = (size_t)L.strips_local() * max_items * L.W * SMK * sizeof(float);
+    return 256 + vt + prow + pcol;
+}
+
+static int symm_matmat_h2_impl(const float* Kp, int64_t n, int64_t first, int64_t stride, double kmax, const float* V,
+                               int64_t k, int64_t ldv, double alpha, double shift, float* Y, int64_t ldy, void* ws,
+                               size_t ws_bytes, hipStream_t st) {
+    const SymLayout L = make_layout<float>(n, first, stride);
+    const int64_t T_loc = L.strips_local();
+    const int64_t max_items = ceil_div(n, ITEM_ROWS);
+    const size_t need = symm_h2_ws_bytes(n, first, stride);
+    if (ws == nullptr || ws_bytes < need) {
+        set_error("rk_symm_matmat_f16x2: workspace %zu B < required %zu B", ws_bytes, need);
+        return RK_ERR_WORKSPACE;
+    }
+    const int64_t npad = round_up(n, 256);
+    unsigned* info = static_cast<unsigned*>(ws);
+    unsigned short* Vt = reinterpret_cast<unsigned short*>(static_cast<char*>(ws) + 256);
+    float* Prow = reinterpret_cast<float*>(Vt + 2 * SMK * npad);
+    float* Pcol = Prow + (size_t)round_up(L.total_rows() * k, 4);
+    int ex;
+    frexp(kmax, &ex);
+    const int ea = 14 - ex;  // stored entries <= kmax < 2^ex: scaled below 2^14
+    if (hipMemsetAsync(info, 0, 256, st) != hipSuccess) return launch_status("rk_symm_matmat_f16x2(memset)");
+    hipLaunchKernelGGL(h2_absmax_kernel, dim3(1024), dim3(256), 0, st, V, n, (int)k, ldv, info);
+    hipLaunchKernelGGL(h2_scale_kernel, dim3(1), dim3(64), 0, st, info, ea);
+    hipLaunchKernelGGL(h2_split_v_kernel, dim3((unsigned)ceil_div((npad / 8) * SMK, 256)), dim3(256), 0, st, V, n, npad,
+                       (int)k, ldv, info, Vt);
+    int rc = launch_status("rk_symm_matmat_f16x2(split)");
+    if (rc != RK_OK) return rc;
+    if (T_loc > 0) {
+        int64_t total_items = 0;
+        for (int64_t t = 0; t < T_loc; ++t) total_items += ceil_div(L.rows(t), ITEM_ROWS);
+        constexpr size_t smem = h2_smem_bytes();
+        static std::atomic<unsigned long long> attr_devs{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(attr_devs.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(symm_strip_h2_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("rk_symm_matmat_f16x2: cannot reserve %zu bytes of LDS", smem);
+                return RK_ERR_LAUNCH;
+            }
+            attr_devs.fetch_or(bit, std::memory_order_release);
+        }
+        const int64_t resident = symm_resident_workgroups(symm_strip_h2_kernel, 2);
+        dim3 grid((unsigned)(total_items < resident ? total_items : resident));
+        hipLaunchKernelGGL(symm_strip_h2_kernel, grid, dim3(SYMM_THREADS), smem, st, Kp, L, Vt, npad,
+                           (float)ldexp(1.0, ea), (int)k, Prow, Pcol, max_items, total_items);
+        rc = launch_status("rk_symm_matmat_f16x2");
+        if (rc != RK_OK) return rc;
+    }
+    hipLaunchKernelGGL((symm_finish_kernel<float>), dim3((unsigned)ceil_div(n * k, 64)), dim3(1024), 0, st, L, (int)k,
+                       (int)k, Prow, Pcol, max_items, (float)alpha, (float)shift, V, ldv, Y, ldy,
+                       reinterpret_cast<const float*>(info + 32));
+    return launch_status("rk_symm_matmat_f16x2(finish)");
+}
+
 }  // namespace rk
 
 using namespace rk;
@@ -859,4 +1224,24 @@ extern "C" int rk_symm_matmat(int dtype, int store_dtype, const void* Kp, int64_
     return symm_matmat_impl<double, double>((const double*)Kp, n, strip_first, strip_stride,
                                             (const double*)V, k, ldv, alpha, diag_shift, (double*)Y, ldy,
                                             ws, ws_bytes, st);
+}
+
+extern "C" size_t rk_symm_matmat_f16x2_ws_bytes(int64_t n, int64_t k, int64_t strip_first, int64_t strip_stride) {
+    if (n <= 0 || k < 1 || k > SMK || strip_stride < 1 || strip_first < 0 || strip_first >= strip_stride) return 0;
+    return symm_h2_ws_bytes(n, strip_first, strip_stride);
+}
+
+extern "C" int rk_symm_matmat_f16x2(const void* Kp, int64_t n, int64_t strip_first, int64_t strip_stride, double kmax,
+                                    const void* V, int64_t k, int64_t ldv, double alpha, double diag_shift, void* Y,
+                                    int64_t ldy, void* ws, size_t ws_bytes, void* stream) {
+    clear_error();
+    int rc = check_layout("rk_symm_matmat_f16x2", RK_F32, RK_F32, n, strip_first, strip_stride);
+    if (rc != RK_OK) return rc;
+    RK_REQUIRE(Kp && V && Y, "rk_symm_matmat_f16x2: null pointer");
+    RK_REQUIRE(k >= 1 && k <= SMK, "rk_symm_matmat_f16x2: k=%lld outside [1,%d]", (long long)k, SMK);
+    RK_REQUIRE(ldv >= k && ldy >= k, "rk_symm_matmat_f16x2: leading dimension too small");
+    RK_REQUIRE(kmax > 0.0 && kmax < 1e30, "rk_symm_matmat_f16x2: kmax must bound the stored entries (got %g)", kmax);
+    RK_REQUIRE(aligned16(Kp) && aligned16(ws), "rk_symm_matmat_f16x2: packed matrix and workspace must be 16-byte aligned");
+    return symm_matmat_h2_impl((const float*)Kp, n, strip_first, strip_stride, kmax, (const float*)V, k, ldv, alpha,
+                               diag_shift, (float*)Y, ldy, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }

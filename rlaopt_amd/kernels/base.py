@@ -142,7 +142,7 @@ class _SymPackBlock:
         """This rank's partial of K x (+ diag_shift x); complete when stride == 1."""
         return get_backend().symm_matmat(
             self.Kp, self.n, x, diag_shift=diag_shift, first=self.first, stride=self.stride,
-            tag="kernel_shard_product",
+            tag="kernel_shard_product", kmax=abs(self.scale) if self.scale != 0.0 else None,
         )
 
     def gemm_ready(self, x) -> bool:

@@ -301,9 +301,12 @@ class HipBackend:
         _lib.check(rc, "rk_kernel_materialize_sympack")
         return Kp
 
-    def symm_matmat(self, Kp, n, V, alpha=1.0, diag_shift=0.0, first=0, stride=1, tag=None):
+    def symm_matmat(self, Kp, n, V, alpha=1.0, diag_shift=0.0, first=0, stride=1, tag=None, kmax=None):
         """alpha * (this rank's partial of) K V + diag_shift * V from the packed triangle; the
-        arithmetic type is V's dtype, the storage type Kp's (float32 storage under float64 V)."""
+        arithmetic type is V's dtype, the storage type Kp's (float32 storage under float64 V).
+        ``kmax``: a bound on the magnitude of the stored entries (the operator's const_scaling) - with it,
+        float32 products of RK_SYMM_F16X2_MIN (4) .. 16 columns run on the 16-bit matrix cores
+        (``rk_symm_matmat_f16x2``)."""
         dev = _req(Kp, V)
         V2, squeeze = _as2d(V)
         if V2.shape[0] != n:
@@ -314,6 +317,18 @@ class HipBackend:
         k = V2.shape[1]
         out = torch.empty((n, k), dtype=V2.dtype, device=dev)
         es = V2.element_size()
+        if (kmax is not None and kmax > 0 and V2.dtype == torch.float32 and Kp.dtype == torch.float32
+                and k >= int(os.environ.get("RK_SYMM_F16X2_MIN", "4")) and os.environ.get("RK_SYMM_F16X2", "1") != "0"):
+            for c0 in range(0, k, 16):
+                kc = min(16, k - c0)
+                ws, wsn = self._workspace(dev, self._lib.rk_symm_matmat_f16x2_ws_bytes(n, kc, first, stride))
+                algo = Kp.numel() * 4 + 2 * n * kc * 4
+                with self._timed(tag or "rk_symm_matmat", dev, algo):
+                    rc = self._lib.rk_symm_matmat_f16x2(
+                        _ptr(Kp), n, first, stride, float(kmax), V2.data_ptr() + c0 * es, kc, ldv, float(alpha),
+                        float(diag_shift), out.data_ptr() + c0 * es, k, _ptr(ws), wsn, _stream(dev))
+                _lib.check(rc, "rk_symm_matmat_f16x2")
+            return out[:, 0] if squeeze else out
         # 5 .. 16 right-hand sides go through the matrix-core strip kernel in ONE pass over the packed
         # triangle (storage and arithmetic type equal); otherwise groups of 4 (register kernel)
         wide_from = 4 if V2.dtype == torch.float64 else 5  # (the float64 register kernel is slow at k = 4)

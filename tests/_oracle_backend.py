@@ -39,7 +39,7 @@ class OracleBackend:
             keep[:hi, lo:hi] = K[:hi, lo:hi]
         return keep.reshape(-1)
 
-    def symm_matmat(self, Kp, n, V, alpha=1.0, diag_shift=0.0, first=0, stride=1, tag=None):
+    def symm_matmat(self, Kp, n, V, alpha=1.0, diag_shift=0.0, first=0, stride=1, tag=None, kmax=None):
         W = 256 if Kp.dtype == torch.float32 else 128
         V2, sq = _two_d(V)
         U = Kp.reshape(n, n).to(V2.dtype)

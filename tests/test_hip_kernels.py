@@ -892,3 +892,45 @@ def test_integration_md_stub_runs_against_the_oracle(be, prec, name, kind):
     # errors surface as the exceptions the stub documents
     with pytest.raises(ValueError):  # more than 16 columns per call: rejected by the C side, status -1
         km(name, A1, A2, 1.0, 1.0, torch.zeros(n2, 17, dtype=dt, device=dev()))
+
+
+@pytest.mark.parametrize("n,k,first,stride", [(300, 5, 0, 1), (1000, 16, 0, 1), (2304, 7, 0, 1), (3000, 10, 0, 1),
+                                             (5000, 16, 0, 1), (4100, 9, 1, 3), (2600, 12, 0, 2), (1500, 1, 0, 1),
+                                             (33, 6, 0, 1)])
+def test_symm_matmat_f16x2_matrix_core_strip_product(be, n, k, first, stride):
+    """rk_symm_matmat_f16x2: the packed symmetric product for up to 16 right-hand sides on the 16-bit matrix
+    cores (two float16 pieces per factor, row reads and transposing reads of one LDS image) against the float64
+    product: per-column error at float32 level for columns of very different magnitude, alpha and the
+    "+ diag_shift V" term, cyclic strip distributions (partials add up), bitwise reproducibility, and agreement
+    with the float32 kernels it replaces."""
+    dt = torch.float32
+    d = 6
+    g = torch.Generator().manual_seed(3 * n + k)
+    X = torch.randn(n, d, dtype=dt, generator=g) / d**0.5
+    scale = 0.75
+    V = torch.randn(n, k, dtype=dt, generator=g) * torch.logspace(-5, 2, k, dtype=dt)
+    Kd = ok.kernel_matrix("matern32", X.double(), X.double(), 0.9, scale)
+    Xd, Vd = X.to(dev()), V.to(dev())
+    want = -1.5 * (Kd @ V.double()) + 0.25 * V.double()
+    parts = []
+    for f in range(stride):
+        Kp = be.sympack_materialize("matern32", Xd, 0.9, scale=scale, first=f, stride=stride)
+        import os as _os
+        _os.environ["RK_SYMM_F16X2_MIN"] = "1"
+        try:
+            got = be.symm_matmat(Kp, n, Vd, alpha=-1.5, diag_shift=0.25 if f == 0 else 0.0, first=f, stride=stride,
+                                 kmax=scale)
+            again = be.symm_matmat(Kp, n, Vd, alpha=-1.5, diag_shift=0.25 if f == 0 else 0.0, first=f, stride=stride,
+                                   kmax=scale)
+        finally:
+            del _os.environ["RK_SYMM_F16X2_MIN"]
+        assert torch.equal(got, again)  # fixed-order tables: reproducible bit for bit
+        parts.append(got.cpu().double())
+        if stride == 1:  # the float32 kernels it replaces (register kernel / float32 matrix cores)
+            old = be.symm_matmat(Kp, n, Vd, alpha=-1.5, diag_shift=0.25)
+            assert float(((got - old).double().norm(dim=0) / old.double().norm(dim=0)).max()) < 5e-6
+    got = sum(parts)
+    err = (got - want).norm(dim=0) / want.norm(dim=0)
+    assert float(err.max()) < 3e-6, (float(err.max()), int(err.argmax()))
+    if first:
+        assert float(parts[first].abs().max()) > 0

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Strip-packed symmetric product ``rk_symm_matmat`` for 1 .. 16 right-hand sides on one MI355X:
-ms per product and GB/s of packed bytes; 5 <= k <= 16 with the matrix-core strip kernel (one pass)
-against groups of 4 through the register kernel (RK_SYMM_WIDE=0)."""
+ms per product and GB/s of packed bytes; float32: the float16-split kernel on the 16-bit matrix cores (f16x2) against
+the float32 matrix-core strip kernel (wide) and groups of 4 through the register kernel (RK_SYMM_WIDE=0)."""
 import argparse
 import json
 import os
@@ -17,9 +17,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=200_000)
     ap.add_argument("--d", type=int, default=64)
-    ap.add_argument("--ks", default="1,4,5,8,10,16")
+    ap.add_argument("--ks", default="1,2,4,5,8,10,16")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--check-rows", type=int, default=1024, help="rows compared with a float64 product (0: none)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     be = get_backend()
@@ -33,26 +34,34 @@ def main():
         V = torch.randn(n, k, dtype=torch.float64, generator=g).to(dt).to(dev)
         rec = {"n": n, "k": k, "packed_GB": round(nbytes / 1e9, 2)}
         outs = {}
-        modes = ["wide", "wide_tr16", "groups_of_4"] if args.dtype == "f32" else ["wide", "groups_of_4"]
-        for mode in (modes if k > 4 else ["register"]):
+        modes = ["f16x2", "wide", "groups_of_4"] if args.dtype == "f32" else ["wide", "groups_of_4"]
+        if k <= 4:
+            modes = ["register", "f16x2"] if (args.dtype == "f32" and k >= 2) else ["register"]
+        want = None
+        if args.check_rows:
+            rows = torch.randperm(n, generator=g)[: args.check_rows].to(dev)
+            want = be.kernel_materialize("rbf", X[rows].double(), X.double(), 1.0) @ V.double()
+        for mode in modes:
             os.environ["RK_SYMM_WIDE"] = "0" if mode == "groups_of_4" else "1"
-            os.environ["RK_SYMM_TR"] = "16" if mode == "wide_tr16" else "32"
-            Y = be.symm_matmat(Kp, n, V)
+            os.environ["RK_SYMM_F16X2_MIN"] = "1"
+            kmax = 1.0 if mode == "f16x2" else None
+            _sm = be.symm_matmat
+            be_symm = lambda Kp_, n_, V_: _sm(Kp_, n_, V_, kmax=kmax)  # noqa: E731
+            Y = be_symm(Kp, n, V)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(args.reps):
-                be.symm_matmat(Kp, n, V)
+                be_symm(Kp, n, V)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.reps
             outs[mode] = Y
             rec[mode] = {"ms": round(ms, 3), "packed_GBps_per_pass": round(nbytes / ms / 1e6, 1)}
+            if want is not None:
+                rec[mode]["max_col_err_vs_f64"] = float(((Y[rows].double() - want).norm(dim=0) / want.norm(dim=0)).max())
         os.environ["RK_SYMM_WIDE"] = "1"
-        os.environ.pop("RK_SYMM_TR", None)
-        if len(outs) >= 2:
-            a, b = outs["wide"].double(), outs["groups_of_4"].double()
-            rec["rel_diff_wide_vs_groups"] = float((a - b).norm() / b.norm())
+        os.environ.pop("RK_SYMM_F16X2_MIN", None)
         print(json.dumps(rec), flush=True)
 
 
