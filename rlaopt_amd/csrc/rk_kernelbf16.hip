@@ -33,9 +33,22 @@
 
 namespace rk {
 
+// RK_BX_F16X2 = 1 (default): TWO float16 pieces per coordinate instead of three bfloat16 ones.  The scaled,
+// centred coordinates obey |x'|^2 <= 32 (the norm bound), so x' 2^10 sits in float16's normal range; with
+// h = f16(x' 2^10), m = f16(x' 2^10 - h) the remainder is below 2^-22 |x'| and the dot product is the sum of
+// THREE exact partial products h.h + h.m + m.h (the dropped m.m is below 2^-22 |x'||y'|) - half the matrix-core
+// work of the six bfloat16 products, for twice their (already negligible) contraction error: 2^-22 instead of
+// 2^-23 relative to |x'||y'|, against the 2^-24 (|x'|^2 + |y'|^2) that the float32 norms carry anyway.
+// Measured (n = 200 000, d = 64, k = 1): see DESIGN.md.  RK_BX_F16X2 = 0 builds the bfloat16 x 3 kernel.
+#ifndef RK_BX_F16X2
+#define RK_BX_F16X2 1
+#endif
+constexpr int BX_NSPLIT = RK_BX_F16X2 ? 2 : 3;  // pieces per coordinate
+constexpr float BX_PRESCALE = RK_BX_F16X2 ? 1024.f : 1.f;              // pieces hold x' times this
+constexpr float BX_UNSCALE = RK_BX_F16X2 ? (1.f / 1048576.f) : 1.f;    // accumulated dot products times this = x'.y'
 constexpr int BX_TI = 128;                      // X1 points per workgroup (4 waves x 32)
 constexpr int BX_SPLIT = 8192;                  // bytes of one split of one image
-constexpr int BX_IMG = 3 * BX_SPLIT;            // bytes of one image (24 KiB)
+constexpr int BX_IMG = BX_NSPLIT * BX_SPLIT;    // bytes of one image (16 KiB / 24 KiB)
 constexpr int BX_LDV = 20;                      // stride of the V tile rows (conflict-free A operand reads)
 constexpr int BX_VROWS = 64;                    // rows of the V / |y|^2 tiles in LDS (largest tile)
 constexpr int BX_FOLD_COLS = 2048;              // columns between folds of the running sums
@@ -55,7 +68,11 @@ struct BxGeo {
     }
 };
 
+#if RK_BX_F16X2
+typedef _Float16 bx_frag __attribute__((ext_vector_type(8)));
+#else
 typedef __bf16 bx_frag __attribute__((ext_vector_type(8)));
+#endif
 typedef float bx_acc __attribute__((ext_vector_type(4)));
 typedef unsigned int bx_u4 __attribute__((ext_vector_type(4)));
 
@@ -86,11 +103,19 @@ gram_split_kernel(const float* __restrict__ X, int64_t ldx, const int64_t* __res
         const int f = c * 8 + u;
         const float x = (live && f < d) ? fmaf(row[f], iw[f], -muw[f]) : 0.f;
         ss += x * x;
+#if RK_BX_F16X2
+        const float xs = x * BX_PRESCALE;
+        const _Float16 h = (_Float16)xs;          // round to nearest even
+        const float r1 = xs - (float)h;           // exact
+        const _Float16 m = (_Float16)r1;
+        hs[u] = __builtin_bit_cast(unsigned short, h); ms[u] = __builtin_bit_cast(unsigned short, m); ls[u] = 0;
+#else
         const unsigned h = bx_bf16_rn(x);
         const float r1 = x - __uint_as_float(h << 16);   // exact
         const unsigned m = bx_bf16_rn(r1);
         const float r2 = r1 - __uint_as_float(m << 16);  // exact
         hs[u] = h; ms[u] = m; ls[u] = bx_bf16_rn(r2);
+#endif
     }
 #pragma unroll
     for (int sh = 1; sh < G::CPR; sh <<= 1) ss += __shfl_xor(ss, sh);
@@ -105,7 +130,80 @@ gram_split_kernel(const float* __restrict__ X, int64_t ldx, const int64_t* __res
     };
     *reinterpret_cast<bx_u4*>(dst) = pack(hs);
     *reinterpret_cast<bx_u4*>(dst + BX_SPLIT) = pack(ms);
-    *reinterpret_cast<bx_u4*>(dst + 2 * BX_SPLIT) = pack(ls);
+    if constexpr (BX_NSPLIT == 3) *reinterpret_cast<bx_u4*>(dst + 2 * BX_SPLIT) = pack(ls);
+}
+
+// ---- RK_BX_F16X2, k > 4: the SECOND product Y^T += V^T P^T on the 16-bit matrix cores too ------------------
+// (it was 4 v_mfma_f32_16x16x4_f32 = 128 matrix-core cycles per 16 x 16 block of P - more than the three float16
+// products of the first one.)  v_mfma_f32_16x16x16_f16 takes P as it sits in the accumulators - element v of a lane
+// is P[j = 4 (lane / 16) + v][i = lane % 16], exactly its B operand (k = 4 (lane / 16) + v) - after a split into
+// two float16 pieces (P 2^10 = h + m, kernel values are <= 1), and V^T as A operand from a pre-split image:
+// per X2 tile [piece][rhs 16][TJ points] float16, every column scaled by a power of two from its largest entry
+// (found on the device), rows padded so that the 8-byte operand reads are bank-conflict free.  Three products
+// (m.h + h.m + h.h) of 16 cycles per block instead of four of 32.
+constexpr int bx_vrowb(int tj) { return tj == 64 ? 136 : 80; }           // bytes of one rhs row of a V tile
+constexpr int bx_vtile_bytes(int tj) { return 2 * 16 * bx_vrowb(tj); }   // 4 352 / 2 560
+constexpr float BX_PSCALE = 1024.f;
+typedef _Float16 bx_h4 __attribute__((ext_vector_type(4)));
+typedef unsigned int bx_u2 __attribute__((ext_vector_type(2)));
+
+// vinfo: [16 absmax bits][16 x 2^eb][16 x 2^-(eb + 10)]
+__global__ void __launch_bounds__(256)
+bx_v_absmax_kernel(const float* __restrict__ V, int64_t n2, int k, int64_t ldv, unsigned* __restrict__ vinfo) {
+    const int c = threadIdx.x & 15;
+    if (c >= k) return;
+    float m = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); r < n2; r += (int64_t)gridDim.x * 16) {
+        const float v = fabsf(V[r * ldv + c]);
+        m = (v == v && v > m) ? v : m;
+    }
+    if (m > 0.f) atomicMax(vinfo + c, __float_as_uint(m));
+}
+__global__ void bx_v_scale_kernel(unsigned* __restrict__ vinfo) {
+    const int c = threadIdx.x;
+    if (c >= 16) return;
+    int eb = 0;
+    const float m = __uint_as_float(vinfo[c]);
+    if (m > 0.f && m < 3.0e38f) {
+        int ex;
+        frexpf(m, &ex);
+        eb = 14 - ex;
+        eb = eb > 100 ? 100 : (eb < -100 ? -100 : eb);
+    }
+    vinfo[16 + c] = __float_as_uint(ldexpf(1.f, eb));
+    vinfo[32 + c] = __float_as_uint(ldexpf(1.f, -eb) / BX_PSCALE);
+}
+// one thread per (point-quad, rhs): 4 consecutive points of one column -> 8 bytes per piece
+template <int TJ>
+__global__ void __launch_bounds__(256)
+bx_v_split_kernel(const float* __restrict__ V, int64_t n2, int64_t n2pad, int k, int64_t ldv,
+                  const unsigned* __restrict__ vinfo, unsigned char* __restrict__ vimg) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int c = (int)(g & 15);
+    const int64_t quad = g >> 4;
+    if (quad >= n2pad / 4) return;
+    const float sb = __uint_as_float(vinfo[16 + c]);
+    unsigned short h[4], m[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int64_t j = quad * 4 + e;
+        const float x = (j < n2 && c < k) ? V[j * ldv + c] * sb : 0.f;
+        const _Float16 hh = (_Float16)x;
+        const _Float16 mm = (_Float16)(x - (float)hh);
+        h[e] = __builtin_bit_cast(unsigned short, hh);
+        m[e] = __builtin_bit_cast(unsigned short, mm);
+    }
+    const int64_t tile = (quad * 4) / TJ;
+    const int jl = (int)((quad * 4) % TJ);
+    unsigned char* dst = vimg + tile * bx_vtile_bytes(TJ) + c * bx_vrowb(TJ) + jl * 2;
+    bx_u2 oh, om;
+    oh.x = h[0] | ((unsigned)h[1] << 16); oh.y = h[2] | ((unsigned)h[3] << 16);
+    om.x = m[0] | ((unsigned)m[1] << 16); om.y = m[2] | ((unsigned)m[3] << 16);
+    *reinterpret_cast<bx_u2*>(dst) = oh;
+    *reinterpret_cast<bx_u2*>(dst + 16 * bx_vrowb(TJ)) = om;
+}
+static size_t bx_vimg_bytes(int64_t n2) {  // vinfo (256 B) + the split image of V (64-point tiles: 68 B per point)
+    return 256 + (size_t)(round_up(n2, 64) / 32) * bx_vtile_bytes(32);
 }
 
 // k <= 4 (full evaluation): a 4-column V tile (50.5 KiB of LDS) and 138 registers admit 3 workgroups per
@@ -113,6 +211,9 @@ gram_split_kernel(const float* __restrict__ X, int64_t ldx, const int64_t* __res
 // symmetric evaluation at 3 per CU - k = 1 fits the LDS - spills 10 registers: 19.5 instead of 18.1 ms.)
 #ifndef RK_BX_WG3
 #define RK_BX_WG3 1
+#endif
+#ifndef RK_BX_SYM_WG3
+#define RK_BX_SYM_WG3 0  // (measured per build: see below)
 #endif
 constexpr int bx_ldv(int kv) { return (RK_BX_WG3 && kv > 0) ? 4 : BX_LDV; }
 constexpr size_t bx_smem_bytes(int kv) {
@@ -145,15 +246,19 @@ struct BxSym {
 // KIND: the kernel function at compile time (with a run-time switch in the tile loop the Matern
 // instantiations spilled up to 280 bytes per lane and ran 22 - 93 % slower)
 template <int KIND, int KV, int NKS, bool SYM>
-__global__ void __launch_bounds__(256, ((RK_BX_WG3 && KV > 0 && !SYM) ? 3 : 2))
+__global__ void __launch_bounds__(256, ((RK_BX_WG3 && (KV > 0 || RK_BX_F16X2) && (!SYM || RK_BX_SYM_WG3)) ? 3 : 2))
 kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, const unsigned char* __restrict__ img2,
                           int64_t n1, int64_t n2, float w, float scale, const float* __restrict__ nx,
                           const float* __restrict__ ny, const float* __restrict__ V, int k, int64_t ldv,
                           int64_t tiles_per_seg, float* __restrict__ part, float* __restrict__ Y, int64_t ldy,
-                          int accumulate, BxSym sym) {
+                          int accumulate, BxSym sym, const unsigned char* __restrict__ vimg,
+                          const unsigned* __restrict__ vinfo) {
     using G = BxGeo<(NKS <= 2 ? 64 : 128)>;
     constexpr int TJ = G::TJ;
     constexpr bool RBF = KIND == RK_RBF;
+    constexpr bool VH = RK_BX_F16X2 && KV == 0;   // second product on the 16-bit matrix cores (V from its split image)
+    constexpr int VROWB = bx_vrowb(TJ);
+    constexpr int VCH = bx_vtile_bytes(TJ) / 16;   // 16-byte chunks of a V tile: 272 / 160
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* XB = smem;                                                  // [2][BX_IMG]
     constexpr int LDV = bx_ldv(KV);
@@ -161,7 +266,7 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
     float* NY = VS + 2 * BX_VROWS * LDV;                                       // [2][BX_VROWS]
     float* CS = NY + 2 * BX_VROWS;                                             // SYM: [2][4][64][KV] + dummy slots
     const float rbf_c = -0.5f * w * w * 1.4426950408889634f;  // exp(-s w^2 / 2) = exp2(rbf_c s)
-    const float m2c = -2.f * rbf_c;
+    const float m2c = -2.f * rbf_c * BX_UNSCALE;  // (the accumulators hold the dot product of the pre-scaled pieces)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -175,7 +280,10 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
     const int64_t t_sym = 2 * rblk + 2;  // SYM: tiles from here on lie beyond the diagonal block
 
     // ---- this wave's X1 operands: 2 blocks of 16 points x 2 k-steps x 3 splits, resident ----------
-    bx_frag bh[2][NKS], bm[2][NKS], bl[2][NKS];
+    bx_frag bh[2][NKS], bm[2][NKS];
+#if !RK_BX_F16X2
+    bx_frag bl[2][NKS];
+#endif
     float nxr[2];
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib) {
@@ -187,11 +295,14 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
             const unsigned char* src = base + G::chunk(r, 4 * ks + lq);
             bh[ib][ks] = __builtin_bit_cast(bx_frag, *reinterpret_cast<const bx_u4*>(src));
             bm[ib][ks] = __builtin_bit_cast(bx_frag, *reinterpret_cast<const bx_u4*>(src + BX_SPLIT));
+#if !RK_BX_F16X2
             bl[ib][ks] = __builtin_bit_cast(bx_frag, *reinterpret_cast<const bx_u4*>(src + 2 * BX_SPLIT));
+#endif
         }
         // (nx has round_up(n1, 128) entries.)  RBF: the exponent is formed directly in base 2,
         // exp2(rbf_c |x|^2 + rbf_c |y|^2 - 2 rbf_c S): the norms are kept pre-multiplied by rbf_c
         nxr[ib] = nx[ip] * (RBF ? rbf_c : 1.f);
+        if constexpr (RBF && RK_BX_F16X2 && KV == 0) nxr[ib] += 10.f;  // the kernel values come out times 2^10 (see the second product)
     }
 
     constexpr int KVS = (SYM && KV > 0) ? KV : 1;
@@ -206,8 +317,10 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
     }
 
     // ---- tile staging: registers -> LDS (the image is copied linearly: it is stored swizzled) -------
-    bx_u4 pre[6];
+    constexpr int NPRE = BX_IMG / 16 / 256;  // 16-byte chunks of an image per thread: 4 / 6
+    bx_u4 pre[NPRE];
     float vr[4], nyr;
+    bx_u4 vq[2];  // VH: this thread's 16-byte chunks of the V tile
     // Every load is unconditional (a conditional load makes the compiler wait for the whole
     // prefetch at the branch join, in front of the arithmetic): rows past n2 re-read row n2 - 1 and
     // columns past k re-read column k - 1 - finite stand-ins that never reach the output, because the
@@ -215,21 +328,33 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
     auto load_tile = [&](int64_t t) {
         const bx_u4* src = reinterpret_cast<const bx_u4*>(img2 + t * BX_IMG);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) pre[q] = src[tid + 256 * q];
-        const int64_t j = t * TJ + ((tid >> 2) & (TJ - 1));
-        const float* vrow = V + (j < n2 ? j : n2 - 1) * ldv;
+        for (int q = 0; q < NPRE; ++q) pre[q] = src[tid + 256 * q];
+        if constexpr (VH) {
+            const bx_u4* vsrc = reinterpret_cast<const bx_u4*>(vimg + t * bx_vtile_bytes(TJ));
+            vq[0] = vsrc[tid < VCH ? tid : VCH - 1];
+            if constexpr (VCH > 256) vq[1] = vsrc[256 + (tid < VCH - 256 ? tid : 0)];
+        } else {
+            const int64_t j = t * TJ + ((tid >> 2) & (TJ - 1));
+            const float* vrow = V + (j < n2 ? j : n2 - 1) * ldv;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c = (tid & 3) * 4 + u;
-            vr[u] = vrow[c < k ? c : k - 1];
+            for (int u = 0; u < 4; ++u) {
+                const int c = (tid & 3) * 4 + u;
+                vr[u] = vrow[c < k ? c : k - 1];
+            }
         }
         nyr = ny[t * TJ + (tid & (TJ - 1))];  // (ny has round_up(n2, 64) entries)
     };
     auto store_tile = [&](int buf) {
         bx_u4* dst = reinterpret_cast<bx_u4*>(XB + buf * BX_IMG);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) dst[tid + 256 * q] = pre[q];
-        if constexpr (LDV == 4) {  // only columns 0 .. 3 are kept (k <= 4)
+        for (int q = 0; q < NPRE; ++q) dst[tid + 256 * q] = pre[q];
+        if constexpr (VH) {
+            bx_u4* vdst = reinterpret_cast<bx_u4*>(VS + buf * BX_VROWS * LDV);  // (5 120 B per buffer >= the tile)
+            if (tid < VCH) vdst[tid] = vq[0];
+            if constexpr (VCH > 256) {
+                if (tid < VCH - 256) vdst[256 + tid] = vq[1];
+            }
+        } else if constexpr (LDV == 4) {  // only columns 0 .. 3 are kept (k <= 4)
             if ((tid & 3) == 0 && tid < 4 * TJ)
                 *reinterpret_cast<float4*>(VS + buf * BX_VROWS * LDV + (tid >> 2) * LDV) = make_float4(vr[0], vr[1], vr[2], vr[3]);
         } else {
@@ -290,6 +415,14 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
                 const unsigned char* src = xb + G::chunk(r, 4 * ks + lq);
                 const bx_frag ah = *reinterpret_cast<const bx_frag*>(src);
                 const bx_frag am = *reinterpret_cast<const bx_frag*>(src + BX_SPLIT);
+#if RK_BX_F16X2
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) {  // small terms first
+                    acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bh[ib][ks], acc[ib], 0, 0, 0);
+                    acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bm[ib][ks], acc[ib], 0, 0, 0);
+                    acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ib][ks], acc[ib], 0, 0, 0);
+                }
+#else
                 const bx_frag al = *reinterpret_cast<const bx_frag*>(src + 2 * BX_SPLIT);
 #pragma unroll
                 for (int ib = 0; ib < 2; ++ib) {  // small terms first
@@ -300,11 +433,13 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
                     acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm[ib][ks], acc[ib], 0, 0, 0);
                     acc[ib] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ib][ks], acc[ib], 0, 0, 0);
                 }
+#endif
             }
             // ---- P = kappa(|x|^2 + |y|^2 - 2 S); Y^T += V^T P^T ------------------------------------
             const float4 ny4 = *reinterpret_cast<const float4*>(nyb + jb * 16 + 4 * lq);
             const float nyv[4] = {ny4.x, ny4.y, ny4.z, ny4.w};
             float qv[4][KVS];  // SYM: this lane's share p[0] v_i0 + p[1] v_i1 of the column sums of rows v = 0 .. 3
+            float pb[2][4];  // VH: the block's kernel values, for the split after the loop
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 float p[2];
@@ -315,13 +450,16 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
                         // -1e-6 gives 1 + 7e-7 instead of 1)
                         p[ib] = __builtin_amdgcn_exp2f(fmaf(acc[ib][v], m2c, nxr[ib] + nyv[v]));
                     } else {
-                        float s = nxr[ib] + nyv[v] - 2.f * acc[ib][v];
+                        float s = nxr[ib] + nyv[v] - (2.f * BX_UNSCALE) * acc[ib][v];
                         s = s > 0.f ? s : 0.f;
                         p[ib] = kernel_value<float>(KIND, s, w);
                     }
                 }
                 const float* vj = vsb + (jb * 16 + 4 * lq + v) * LDV;
-                if constexpr (KV == 0) {
+                if constexpr (VH) {
+                    pb[0][v] = p[0];
+                    pb[1][v] = p[1];
+                } else if constexpr (KV == 0) {
                     const float av = vj[lr];  // A operand: V[j = 4 (lane / 16) + v][rhs = lane % 16]
 #pragma unroll
                     for (int ib = 0; ib < 2; ++ib)
@@ -343,6 +481,33 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
 #pragma unroll
                         for (int c = 0; c < KV; ++c) qv[v][c] = fmaf(p[0], vi[0][c], p[1] * vi[1][c]);
                     }
+                }
+            }
+            if constexpr (VH) {
+                // A = V^T pieces: rhs lr, points jb * 16 + 4 lq .. + 4 (8 bytes per piece)
+                const unsigned char* va = reinterpret_cast<const unsigned char*>(vsb) + lr * VROWB + (jb * 16 + 4 * lq) * 2;
+                const bx_h4 vh = __builtin_bit_cast(bx_h4, *reinterpret_cast<const bx_u2*>(va));
+                const bx_h4 vm = __builtin_bit_cast(bx_h4, *reinterpret_cast<const bx_u2*>(va + 16 * VROWB));
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) {
+                    // split of P 2^10 (RBF: the factor rides in the exponent) into two float16 pieces, two values per
+                    // conversion: h = toward-zero rounding (v_cvt_pkrtz_f16_f32), m = the exact remainder rounded the
+                    // same way: P 2^10 = h + m + O(2^-21 P)
+                    typedef __fp16 bx_p2 __attribute__((ext_vector_type(2)));
+                    bx_u2 phu, pmu;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float x0 = RBF ? pb[ib][2 * e] : pb[ib][2 * e] * BX_PSCALE;
+                        const float x1 = RBF ? pb[ib][2 * e + 1] : pb[ib][2 * e + 1] * BX_PSCALE;
+                        const bx_p2 h2 = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+                        const bx_p2 m2 = __builtin_amdgcn_cvt_pkrtz(x0 - (float)h2[0], x1 - (float)h2[1]);
+                        if (e == 0) { phu.x = __builtin_bit_cast(unsigned, h2); pmu.x = __builtin_bit_cast(unsigned, m2); }
+                        else { phu.y = __builtin_bit_cast(unsigned, h2); pmu.y = __builtin_bit_cast(unsigned, m2); }
+                    }
+                    const bx_h4 ph = __builtin_bit_cast(bx_h4, phu), pm = __builtin_bit_cast(bx_h4, pmu);
+                    yacc[ib] = __builtin_amdgcn_mfma_f32_16x16x16f16(vm, ph, yacc[ib], 0, 0, 0);
+                    yacc[ib] = __builtin_amdgcn_mfma_f32_16x16x16f16(vh, pm, yacc[ib], 0, 0, 0);
+                    yacc[ib] = __builtin_amdgcn_mfma_f32_16x16x16f16(vh, ph, yacc[ib], 0, 0, 0);
                 }
             }
             if constexpr (SYM && KV > 0) {
@@ -376,9 +541,10 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
         // (not for d > 64: there the hint costs registers the three-workgroup variants do not have)
         if constexpr (NKS <= 2) {
 #pragma unroll
-            for (int q = 0; q < 128; ++q) {
+            // (three float16 products per block instead of six: half as many matrix-core instructions per vector one)
+            for (int q = 0; q < (RK_BX_F16X2 ? 64 : 128); ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, RK_BX_F16X2 ? 3 : 1, 0);
             }
         }
         if (((t - t_lo) & (BX_FOLD_COLS / TJ - 1)) == BX_FOLD_COLS / TJ - 1) {
@@ -422,6 +588,7 @@ kmat_matmat_bf16x3_kernel(int kind, const unsigned char* __restrict__ img1, cons
         float sum;
         if constexpr (KV == 0) {
             sum = yl[il * 16 + c];
+            if constexpr (VH) sum *= __uint_as_float(vinfo[32 + c]);  // undo the column's scale and the 2^10 of P
         } else {
             const float4 q = *reinterpret_cast<const float4*>(yl + (il * KV + c) * 4);
             sum = (q.x + q.y) + (q.z + q.w);
@@ -527,8 +694,11 @@ size_t bx_sym_ws_bytes(int64_t n, int64_t k) {
 static size_t bx_float_bytes(int64_t n1, int64_t n2) {
     return (size_t)round_up((2 * 128 + round_up(n1, BX_TI) + round_up(n2, 64)) * (int64_t)sizeof(float), 256);
 }
-size_t bx_aux_bytes(int64_t n1, int64_t n2) {
-    return bx_float_bytes(n1, n2) + (size_t)(round_up(n1, BX_TI) / 32 + round_up(n2, 64) / 32) * BX_IMG;
+static size_t bx_img_bytes(int64_t n1, int64_t n2) {
+    return (size_t)(round_up(n1, BX_TI) / 32 + round_up(n2, 64) / 32) * BX_IMG;
+}
+size_t bx_aux_bytes(int64_t n1, int64_t n2) {  // floats | images of both point sets | vinfo + split image of V
+    return bx_float_bytes(n1, n2) + bx_img_bytes(n1, n2) + bx_vimg_bytes(n2);
 }
 int64_t bx_tile_points(int64_t d) { return d <= 64 ? 64 : 32; }
 // a caller-kept image of the X2 side of a product: |y'|^2 of the padded points, then their split images
@@ -572,11 +742,37 @@ int launch_kmatmat_bf16x3(int kind, const float* X1, int64_t n1, int64_t ldx1, c
                                ldx2, idx2, n2, n2pad, d, iw, muw, img2, nyp);
     }
     const int nks = d <= 32 ? 1 : (d <= 64 ? 2 : 4);
+    // k > 4 (float16 build): the split image of V for the second product, behind the images of the point sets
+    unsigned* vinfo = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(aux) + bx_float_bytes(n1, n2) +
+                                                  bx_img_bytes(n1, n2));
+    unsigned char* vimg = reinterpret_cast<unsigned char*>(vinfo) + 256;
+    if (RK_BX_F16X2 && k > 4) {
+        if (hipMemsetAsync(vinfo, 0, 256, st) != hipSuccess) return launch_status("rk_kernel_matmat(bf16x3 memset)");
+        hipLaunchKernelGGL(bx_v_absmax_kernel, dim3(512), dim3(256), 0, st, V, n2, k, ldv, vinfo);
+        hipLaunchKernelGGL(bx_v_scale_kernel, dim3(1), dim3(64), 0, st, vinfo);
+        const dim3 vg((unsigned)ceil_div((n2pad / 4) * 16, 256));
+        if (tj == 64)
+            hipLaunchKernelGGL(bx_v_split_kernel<64>, vg, dim3(256), 0, st, V, n2, n2pad, k, ldv, vinfo, vimg);
+        else
+            hipLaunchKernelGGL(bx_v_split_kernel<32>, vg, dim3(256), 0, st, V, n2, n2pad, k, ldv, vinfo, vimg);
+    }
     dim3 grid((unsigned)ceil_div(n1, BX_TI), (unsigned)S);
+    // RK_BX_LDS_PAD: extra dynamic LDS per workgroup (bytes, < 20 000) - lowers the number of resident workgroups
+    // per CU, which matters when this product shares the device with a latency-bound chain on another stream
+    // A caller-kept X2 image marks the SAP row oracle (rk_kernel_matmat_cached): that product runs BESIDE the
+    // step's latency-bound chain (block preconditioner, power iteration: ~100 small kernels on a high-priority
+    // stream).  At three workgroups per CU it leaves the chain no slots until it has finished (measured: no chain
+    // kernel starts inside the product, step 3.3 ms); at two the chain runs beside it (2.8 ms) although the
+    // product itself is slower (1.8 instead of 1.6 ms) - the step is bound by the chain, not by the product.
+    size_t lds_pad = x2_image != nullptr ? 12288 : 0;
+    if (const char* e = getenv("RK_BX_LDS_PAD")) {
+        const long v = atol(e);
+        if (v >= 0 && v < 20000) lds_pad = (size_t)v & ~(size_t)15;
+    }
 #define RK_BX_N(RBFV, KVV, NKSV)                                                                           \
-    hipLaunchKernelGGL((kmat_matmat_bf16x3_kernel<RBFV, KVV, NKSV, false>), grid, dim3(256), bx_smem_bytes(KVV), \
+    hipLaunchKernelGGL((kmat_matmat_bf16x3_kernel<RBFV, KVV, NKSV, false>), grid, dim3(256), bx_smem_bytes(KVV) + lds_pad, \
                        st, kind, img1, img2, n1, n2, w, scale, nxp, nyp, V, k, ldv, tiles_per_seg, part, Y, ldy, \
-                       accumulate, BxSym{})
+                       accumulate, BxSym{}, vimg, vinfo)
 #define RK_BX(RBFV, KVV)                                                                                   \
     do {                                                                                                   \
         if (nks == 1) RK_BX_N(RBFV, KVV, 1);                                                               \
@@ -633,7 +829,8 @@ int launch_kmatmat_bf16x3_sym(int kind, const float* X, int64_t n, int64_t ldx, 
 #define RK_BXS_N(RBFV, KVV, NKSV)                                                                          \
     hipLaunchKernelGGL((kmat_matmat_bf16x3_kernel<RBFV, KVV, NKSV, true>), grid, dim3(256),               \
                        bx_sym_smem_bytes(KVV), st, kind, img, img, n, n, w, scale, nrm, nrm, V, k, ldv,    \
-                       (int64_t)0, (float*)nullptr, (float*)nullptr, (int64_t)0, 0, sym)
+                       (int64_t)0, (float*)nullptr, (float*)nullptr, (int64_t)0, 0, sym,                   \
+                       (const unsigned char*)nullptr, (const unsigned*)nullptr)
 #define RK_BXS(RBFV, KVV)                                                                                  \
     do {                                                                                                   \
         if (nks == 1) RK_BXS_N(RBFV, KVV, 1);                                                              \
