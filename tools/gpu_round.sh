@@ -3,17 +3,21 @@
 # Usage (on the box, from the repo root): bash tools/gpu_round.sh <tag>
 set -o pipefail
 TAG=${1:-r01}
+PART=${2:-all}   # a: tests, bench, rocprof / PMC of the bench; b: everything else; all: both (needs > 20 minutes)
 OUT=gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+if [ "$PART" != "b" ]; then
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/${TAG}_smoke.log 2>&1; tail -1 $OUT/${TAG}_smoke.log
-timeout -k 10 700 python -m pytest tests -m gpu -q -x > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest EXIT $?"; tail -3 $OUT/${TAG}_pytest_gpu.log
+timeout -k 10 800 python -m pytest tests -m gpu -q -x > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest EXIT $?"; tail -3 $OUT/${TAG}_pytest_gpu.log
 timeout -k 10 300 python bench.py > $OUT/${TAG}_bench_n1.log 2>&1 && echo "bench ok" && tail -1 $OUT/${TAG}_bench_n1.log | cut -c1-400
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o ${TAG} -- python3 bench.py --no-cpu-baseline --no-solve > $OUT/${TAG}_bench_under_rocprof.log 2>&1 && echo "rocprof stats ok"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o ${TAG} -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-solve > $OUT/${TAG}_pmc_fetch.log 2>&1 && echo "pmc fetch ok"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o ${TAG} -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-solve > $OUT/${TAG}_pmc_write.log 2>&1 && echo "pmc write ok"
 # matrix-core counters of the Nystrom assembly GEMMs (own pass: SQ + GRBM only)
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_mfma -o ${TAG} -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-solve > $OUT/${TAG}_pmc_mfma.log 2>&1 && echo "pmc mfma ok"
+fi
+if [ "$PART" = "a" ]; then exit 0; fi
 # the two "next" rows of SURVEY 8(f): ASkotch (config 5) and LSQR (config 4)
 timeout -k 10 300 python3 tools/bench_sap.py > $OUT/${TAG}_bench_sap.log 2>&1 && echo "sap ok" && tail -1 $OUT/${TAG}_bench_sap.log | cut -c1-300
 timeout -k 10 300 python3 tools/bench_lsqr.py > $OUT/${TAG}_bench_lsqr.log 2>&1 && echo "lsqr ok" && tail -1 $OUT/${TAG}_bench_lsqr.log | cut -c1-300
