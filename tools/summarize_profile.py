@@ -88,37 +88,35 @@ with open(f"{dst}/{tag}_summary.md", "w") as f:
             f"(kernel-trace rows of that kernel, long ones only): **{len(shard)} launches, "
             f"average {shard_avg_ms:.3f} ms** (rocprofv3) vs {bench['roofline']['avg_launch_ms']:.3f} ms "
             f"(HIP events inside bench.py, un-profiled run).\n\n")
-    # matrix-core evidence: the Nystrom sketch GEMMs (K_panel @ Omega, then U = Y M twice)
+    # matrix-core evidence: the Nystrom sketch product Y = K Omega (rk_symm_gemm: float16 split on the 16-bit cores)
     import re as _re
     mwl = _re.search(r"n=(\d+) d=\d+ k=\d+ nystrom_rank=(\d+)", bench["config"]["workload"])
-    gem = [r for r in rows if "gemm_kernel<float, float" in r["Name"]]
+    gem = [r for r in rows if "symgemm_kernel" in r["Name"]]
     if mwl and gem:
         nn, rr = int(mwl.group(1)), int(mwl.group(2))
-        flops = 2.0 * nn * nn * rr / bench["n_gpus"] + 2 * (2.0 * nn * rr * rr) / bench["n_gpus"]
-        tot = sum(float(r["TotalDurationNs"]) for r in gem) / 1e9
-        f.write("## Matrix cores (exact-fp32 MFMA GEMMs of the Nystrom assembly)\n\n")
-        f.write(f"`gemm_kernel<float,float,...>`: {sum(int(r['Calls']) for r in gem)} launches, {tot * 1e3:.1f} ms "
-                f"for 2 n^2 r + 4 n r^2 = {flops:.3e} flop -> **{flops / tot / 1e12:.1f} TFLOP/s** "
-                f"({100 * flops / tot / 157.3e12:.0f} % of the 157.3 TFLOP/s fp32 matrix peak, v_mfma_f32_32x32x2_f32).\n\n")
-    # matrix-core busy counter (own --pmc pass), if collected
+        flops = 2.0 * nn * nn * rr / bench["n_gpus"]  # float32-equivalent, per launch
+        md = med.get(gem[0]["Name"], (float(gem[0]["AverageNs"]) / 1e3, 0.0))[0] * 1e-6  # s
+        terms = 6 if "SgBf16" in gem[0]["Name"] else 3
+        f.write("## Matrix cores: the Nystrom sketch product Y = K Omega from the packed strips (`rk_symm_gemm`)\n\n")
+        f.write(f"`symgemm_kernel`: {sum(int(r['Calls']) for r in gem)} launches (assembly + its warm repeat), median {md * 1e3:.1f} ms for "
+                f"2 n^2 r = {flops:.3e} flop float32-equivalent -> **{flops / md / 1e12:.0f} TFLOP/s float32-equivalent = "
+                f"{terms * flops / md / 1e15:.2f} PFLOP/s on the 16-bit matrix cores** ({terms} exact products per pair; "
+                f"{100 * terms * flops / md / 2.5e15:.0f} % of their 2.5 PFLOP/s dense peak).\n\n")
     mf = f"{src}/{tag}_pmc_mfma/{tag}_counter_collection.csv"
-    if os.path.exists(mf):
+    if os.path.exists(mf) and gem:
         acc = {}
         for r in csv.DictReader(open(mf)):
-            if "gemm_kernel<float, float" in r["Kernel_Name"]:
+            if "symgemm_kernel" in r["Kernel_Name"]:
                 acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
         if acc.get("SQ_VALU_MFMA_BUSY_CYCLES") and acc.get("GRBM_GUI_ACTIVE"):
             busy = sum(acc["SQ_VALU_MFMA_BUSY_CYCLES"])
             gui = sum(acc["GRBM_GUI_ACTIVE"])
-            sqb = sum(acc.get("SQ_BUSY_CYCLES", [0.0]))
-            # SQ_VALU_MFMA_BUSY_CYCLES is summed over the SIMDs (it equals #MFMA x 64 cycles: one
-            # v_mfma_f32_32x32x2_f32 = 4096 flop at 64 flop/clk/SIMD); GRBM_GUI_ACTIVE is reported
-            # once per XCD (8 of them) -> utilisation = busy / (gui / 8 x 1024 SIMDs)
+            # SQ_VALU_MFMA_BUSY_CYCLES is summed over the SIMDs (#MFMA x 16 cycles for v_mfma_f32_16x16x32_f16);
+            # GRBM_GUI_ACTIVE is reported once per XCD (8 of them) -> utilisation = busy / (gui / 8 x 1024 SIMDs)
             util = busy / (gui / 8.0 * 1024.0)
-            f.write(f"PMC over the same GEMM launches (own pass): SQ_VALU_MFMA_BUSY_CYCLES = {busy:.4g} "
-                    f"(= {busy / 64:.4g} MFMA x 64 cycles; the flop count above / 4096 = {flops / 4096:.4g}), "
-                    f"GRBM_GUI_ACTIVE = {gui:.4g} summed over 8 XCDs, SQ_BUSY_CYCLES = {sqb:.4g} -> "
-                    f"**matrix-core utilisation {100 * util:.1f} %** of the 1024 SIMDs' MFMA issue slots.\n\n")
+            f.write(f"PMC over the same launches (own pass): SQ_VALU_MFMA_BUSY_CYCLES = {busy:.4g} (= {busy / 16:.4g} MFMA x 16 "
+                    f"cycles), GRBM_GUI_ACTIVE = {gui:.4g} summed over 8 XCDs -> **matrix cores busy {100 * util:.1f} %** of the "
+                    f"1024 SIMDs' cycles.\n\n")
     # the "next" rows: ASkotch and LSQR benches
     for name, title in (("sap", "ASkotch / SAP (BASELINE config 5, tools/bench_sap.py)"),
                         ("lsqr", "LSQR + SkPre (BASELINE config 4, tools/bench_lsqr.py)")):
