@@ -187,6 +187,26 @@ int rk_symm_gemm(const void* Kp, int64_t n, int64_t strip_first, int64_t strip_s
                  const void* V, int64_t k, int64_t ldv, double alpha, void* Y, int64_t ldy, void* ws,
                  size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Transport  [a5, e]: RCCL behind the C ABI, one communicator per rank (one rank per GPU).
+ * Replaces the reference's worker processes, pickled task / result queues and host staging
+ * (rlaopt/linops/base.py:157-176,202-267): ROW-mode concat -> rk_comm_allgather, COLUMN-mode /
+ * transpose sum -> rk_comm_allreduce_sum (rlaopt/linops/distributed.py:40-50,81-91), partial
+ * products of cyclically dealt strips -> rk_comm_reduce_scatter_sum.  librk_hip.so does not link
+ * RCCL: the library is bound at first use (the copy already mapped into the process - e.g.
+ * PyTorch's - or the system's librccl.so).  rk_comm_unique_id: rank 0 fills 128 bytes, the caller
+ * ships them to the other ranks by any side channel (a file, MPI, torch.distributed's store);
+ * rk_comm_create is collective over the ranks.  Buffers are device pointers, `count` in elements of
+ * `dtype`; all-gather / reduce-scatter take the per-rank count; every call is queued on `stream`.
+ * ---------------------------------------------------------------------------------- */
+int rk_comm_unique_id(void* id128);
+int rk_comm_create(void** comm, int nranks, int rank, const void* id128);
+int rk_comm_destroy(void* comm);
+int rk_comm_allreduce_sum(void* comm, void* buf, int64_t count, int dtype, void* stream);
+int rk_comm_allgather(void* comm, const void* send, void* recv, int64_t count_per_rank, int dtype, void* stream);
+int rk_comm_reduce_scatter_sum(void* comm, const void* send, void* recv, int64_t count_per_rank, int dtype,
+                               void* stream);
+
 /* Wire buffer of the reduce-scatter that sums the ranks' partial products  [a5, e]: out (slots x (step k + t)),
  * slot r = [ rows r step .. (r + 1) step of the n x k partial (zero beyond row n) | tail (t float64 values,
  * converted) ], in `dtype`.  One launch instead of a zero-fill, a strided copy and a broadcast; the transport

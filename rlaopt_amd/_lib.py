@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("RK_HIP_LIBRARY") or os.path.join(_HERE, "librk_hip.so
 RK_F32, RK_F64 = 0, 1
 GRAM_MAX_NORM2 = 32.0  # RK_GRAM_MAX_NORM2 of include/rk.h
 KIND_IDS = {"rbf": 0, "laplace": 1, "matern12": 2, "matern32": 3, "matern52": 4}
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 # name -> (restype, argtypes); must list every symbol declared in include/rk.h
 SIGNATURES = {
@@ -77,6 +77,12 @@ SIGNATURES = {
         [c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64, c_int64, c_double, c_void_p, c_int64,
          c_void_p, c_size_t, c_void_p],
     ),
+    "rk_comm_unique_id": (c_int, [c_void_p]),
+    "rk_comm_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_void_p]),
+    "rk_comm_destroy": (c_int, [c_void_p]),
+    "rk_comm_allreduce_sum": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "rk_comm_allgather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "rk_comm_reduce_scatter_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "rk_spmd_pack": (
         c_int,
         [c_int, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p],

@@ -80,11 +80,66 @@ def _account(kind: str, nbytes: int, factor: float, group) -> None:
     wire_stats["by_kind"][kind] = wire_stats["by_kind"].get(kind, 0) + 1
 
 
+# ---- optional: the collectives through the C ABI's own RCCL transport (RK_COMM=abi) ---------------------------
+# Default: torch.distributed moves the buffers (backend "nccl" = RCCL).  With RK_COMM=abi and device buffers the
+# three collectives go through rk_comm_* (include/rk.h) instead - the transport a maintainer binding the C ABI into
+# the reference would use; the communicator is created once per process (rank 0's unique id travels through the
+# torch.distributed store).
+_abi_comm = {"handle": None, "size": 0}
+
+
+def _use_abi_comm(t: torch.Tensor, group) -> bool:
+    return (os.environ.get("RK_COMM", "") == "abi" and t.is_cuda and t.dtype in (torch.float32, torch.float64)
+            and group is None and td.get_backend(group) == "nccl")
+
+
+def _abi(group=None):
+    import ctypes
+
+    from . import _lib
+
+    if _abi_comm["handle"] is None:
+        lib = _lib.load()
+        rank, size = td.get_rank(group), td.get_world_size(group)
+        box = [None]
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            _lib.check(lib.rk_comm_unique_id(buf), "rk_comm_unique_id")
+            box = [bytes(buf.raw)]
+        td.broadcast_object_list(box, src=0, group=group)
+        h = ctypes.c_void_p()
+        _lib.check(lib.rk_comm_create(ctypes.byref(h), size, rank, box[0]), "rk_comm_create")
+        _abi_comm.update(handle=h, size=size)
+    return _abi_comm["handle"]
+
+
+def _abi_dt(t):
+    return 0 if t.dtype == torch.float32 else 1
+
+
+def _abi_stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def shutdown_abi_comm() -> None:
+    """Destroy the RK_COMM=abi communicator (tests; process exit does not need it)."""
+    from . import _lib
+
+    if _abi_comm["handle"] is not None:
+        _lib.check(_lib.load().rk_comm_destroy(_abi_comm["handle"]), "rk_comm_destroy")
+        _abi_comm.update(handle=None, size=0)
+
+
 def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     """In-place sum over ranks (no-op without a group)."""
     if spmd_active(group):
         _account("all_reduce", t.numel() * t.element_size(), 2.0, group)
-        if _host_staged(t, group):
+        if _use_abi_comm(t, group) and t.is_contiguous():
+            from . import _lib
+
+            _lib.check(_lib.load().rk_comm_allreduce_sum(_abi(group), t.data_ptr(), t.numel(), _abi_dt(t), _abi_stream(t)),
+                       "rk_comm_allreduce_sum")
+        elif _host_staged(t, group):
             h = t.cpu()
             td.all_reduce(h, op=td.ReduceOp.SUM, group=group)
             t.copy_(h)
@@ -126,6 +181,13 @@ def all_gather_rows(local: torch.Tensor, sizes, group=None) -> torch.Tensor:
         host = torch.empty((size * step, k), dtype=loc.dtype)
         td.all_gather_into_tensor(host, loc.cpu().contiguous(), group=group)
         out = host.to(loc.device)
+    elif _use_abi_comm(loc, group):
+        from . import _lib
+
+        out = torch.empty((size * step, k), dtype=loc.dtype, device=loc.device)
+        src = loc.contiguous()
+        _lib.check(_lib.load().rk_comm_allgather(_abi(group), src.data_ptr(), out.data_ptr(), src.numel(), _abi_dt(src),
+                                                 _abi_stream(src)), "rk_comm_allgather")
     else:
         out = torch.empty((size * step, k), dtype=loc.dtype, device=loc.device)
         td.all_gather_into_tensor(out, loc.contiguous(), group=group)
@@ -161,6 +223,12 @@ def reduce_scatter_rows(partial: torch.Tensor, n: int, tail: torch.Tensor | None
         host = torch.empty(slot, dtype=buf.dtype)
         td.reduce_scatter_tensor(host, buf.cpu().reshape(-1), op=td.ReduceOp.SUM, group=group)
         out = host.to(buf.device)
+    elif _use_abi_comm(buf, group):
+        from . import _lib
+
+        out = torch.empty(slot, dtype=buf.dtype, device=buf.device)
+        _lib.check(_lib.load().rk_comm_reduce_scatter_sum(_abi(group), buf.data_ptr(), out.data_ptr(), slot, _abi_dt(buf),
+                                                          _abi_stream(buf)), "rk_comm_reduce_scatter_sum")
     else:
         out = torch.empty(slot, dtype=buf.dtype, device=buf.device)
         td.reduce_scatter_tensor(out, buf.view(-1), op=td.ReduceOp.SUM, group=group)

@@ -120,3 +120,16 @@ def test_integration_stub_signature_matches_the_binding():
     assert list(lib.rk_kernel_matmat_ws_bytes.argtypes) == list(argtypes)
     assert ns["_KIND"] == {"RBF": 0, "Laplace": 1, "Matern12": 2, "Matern32": 3, "Matern52": 4}
     assert {k: v for k, v in _lib.KIND_IDS.items()} == {"rbf": 0, "laplace": 1, "matern12": 2, "matern32": 3, "matern52": 4}
+
+
+def test_comm_exports_validate_arguments_without_a_gpu():
+    """rk_comm_*: bad ranks and null pointers are rejected before RCCL is touched."""
+    from rlaopt_amd import _lib
+
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    ident = ctypes.create_string_buffer(128)
+    assert lib.rk_comm_create(ctypes.byref(h), 2, 2, ident) == -1 and b"rank 2 outside" in lib.rk_last_error()
+    assert lib.rk_comm_create(None, 1, 0, ident) == -1
+    assert lib.rk_comm_unique_id(None) == -1
+    assert lib.rk_comm_destroy(None) == 0

@@ -18,8 +18,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("backend,world,n", [("gloo", 2, 3001), ("gloo", 3, 2000), ("nccl", 1, 3001)])
+@pytest.mark.parametrize("backend,world,n", [("gloo", 2, 3001), ("gloo", 3, 2000), ("nccl", 1, 3001), ("nccl-abi", 1, 3001)])
 def test_spmd_on_gpu(backend, world, n):
+    """("nccl-abi": the single-rank RCCL group with the collectives routed through the C ABI's own transport,
+    rk_comm_* - RK_COMM=abi.)"""
+    abi = backend == "nccl-abi"
+    backend = "nccl" if abi else backend
     port = _free_port()
     procs = []
     for rank in range(world):
@@ -28,6 +32,8 @@ def test_spmd_on_gpu(backend, world, n):
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         if backend == "nccl":
             env["RK_FORCE_SPMD"] = "1"
+        if abi:
+            env["RK_COMM"] = "abi"
         procs.append(subprocess.Popen(
             [sys.executable, os.path.join(HERE, "_dist_gpu_worker.py"), backend, str(n)],
             env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
@@ -44,3 +50,38 @@ def test_spmd_on_gpu(backend, world, n):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {rank} failed:\n{out[-3000:]}"
     assert outs[0].count("DIST-GPU-OK") == 2
+
+
+def test_rk_comm_transport_single_rank():
+    """rk_comm_* (include/rk.h): unique id, communicator, the three collectives on device buffers
+    (a world of one: every collective is the identity) and the error path, through the raw C ABI."""
+    import ctypes
+
+    import torch
+
+    from rlaopt_amd import _lib
+
+    lib = _lib.load()
+    ident = ctypes.create_string_buffer(128)
+    _lib.check(lib.rk_comm_unique_id(ident), "rk_comm_unique_id")
+    assert any(ident.raw)
+    comm = ctypes.c_void_p()
+    _lib.check(lib.rk_comm_create(ctypes.byref(comm), 1, 0, ident), "rk_comm_create")
+    assert comm.value
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for dt, code in ((torch.float32, 0), (torch.float64, 1)):
+        x = torch.randn(1000, 3, dtype=dt, device=dev)
+        ref = x.clone()
+        _lib.check(lib.rk_comm_allreduce_sum(comm, x.data_ptr(), x.numel(), code, st), "allreduce")
+        out = torch.empty_like(x)
+        _lib.check(lib.rk_comm_allgather(comm, x.data_ptr(), out.data_ptr(), x.numel(), code, st), "allgather")
+        rs = torch.empty_like(x)
+        _lib.check(lib.rk_comm_reduce_scatter_sum(comm, x.data_ptr(), rs.data_ptr(), x.numel(), code, st), "reduce_scatter")
+        torch.cuda.synchronize()
+        assert torch.equal(x, ref) and torch.equal(out, ref) and torch.equal(rs, ref)
+    with pytest.raises(ValueError):
+        _lib.check(lib.rk_comm_allreduce_sum(comm, None, 4, 0, st), "allreduce")
+    with pytest.raises(ValueError):
+        _lib.check(lib.rk_comm_allreduce_sum(comm, x.data_ptr(), 4, 7, st), "allreduce")
+    _lib.check(lib.rk_comm_destroy(comm), "rk_comm_destroy")

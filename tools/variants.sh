@@ -9,7 +9,7 @@ while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   out=build_var/$name; mkdir -p $out
   objs=""
-  for f in rk_skinny.hip rk_kernelmat.hip rk_kernelmfma.hip rk_kernelbf16.hip rk_gemm.hip rk_symm.hip rk_symgemm.hip rk_normal.hip rk_api.cpp; do
+  for f in rk_skinny.hip rk_kernelmat.hip rk_kernelmfma.hip rk_kernelbf16.hip rk_gemm.hip rk_symm.hip rk_symgemm.hip rk_normal.hip rk_api.cpp rk_comm.cpp; do
     o=$out/${f%.*}.o
     slp=""  # same per-file flags as the Makefile
     case $f in rk_skinny.hip|rk_symm.hip|rk_normal.hip) slp="-fno-slp-vectorize";; esac
@@ -17,7 +17,7 @@ while [ $# -ge 2 ]; do
     objs="$objs $o"
   done
   wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $out/librk_hip.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $out/librk_hip.so -ldl
   rm -f $objs
   echo "built $out/librk_hip.so ($flags)"
 done
