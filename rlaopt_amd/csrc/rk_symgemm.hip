@@ -124,14 +124,24 @@ struct SgBf16 {  // three bfloat16 pieces, six products
 constexpr int SG_INFO_BYTES = 3 * 1024 * 4;  // kpad <= 1024
 __global__ void __launch_bounds__(256)
 sg_absmax_kernel(const float* __restrict__ V, int64_t n, int64_t k, int64_t ldv, unsigned* __restrict__ out) {
-    const int64_t c = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
-    if (c >= k) return;
+    __shared__ float red[4][64];  // one atomic per column and workgroup
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + cx;
     float m = 0.f;
-    for (int64_t r = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.y * 4) {
-        const float v = fabsf(V[r * ldv + c]);
-        m = (v == v && v > m) ? v : m;
+    if (c < k) {
+        for (int64_t r = (int64_t)blockIdx.y * 4 + ry; r < n; r += (int64_t)gridDim.y * 4) {
+            const float v = fabsf(V[r * ldv + c]);
+            m = (v == v && v > m) ? v : m;
+        }
     }
-    if (m > 0.f) atomicMax(out + c, __float_as_uint(m));
+    red[ry][cx] = m;
+    __syncthreads();
+    if (ry == 0 && c < k) {
+        float t = red[0][cx];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) t = red[q][cx] > t ? red[q][cx] : t;
+        if (t > 0.f) atomicMax(out + c, __float_as_uint(t));
+    }
 }
 
 // scale factors per column: info[kpad + c] <- 2^eB, info[2 kpad + c] <- alpha 2^-(eA + eB)

@@ -640,14 +640,23 @@ __device__ __forceinline__ h2_acc h2_mfma3(const h2_u4 (&a)[2], const h2_u4 (&b)
 // largest |V[:, c]| per column (float bits; non-negative floats order like integers)
 __global__ void __launch_bounds__(256)
 h2_absmax_kernel(const float* __restrict__ V, int64_t n, int k, int64_t ldv, unsigned* __restrict__ out) {
-    const int c = threadIdx.x & 15;
-    if (c >= k) return;
+    __shared__ float red[16][16];  // one atomic per column and workgroup
+    const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
     float m = 0.f;
-    for (int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); r < n; r += (int64_t)gridDim.x * 16) {
-        const float v = fabsf(V[r * ldv + c]);
-        m = (v == v && v > m) ? v : m;
+    if (c < k) {
+        for (int64_t r = (int64_t)blockIdx.x * 16 + g; r < n; r += (int64_t)gridDim.x * 16) {
+            const float v = fabsf(V[r * ldv + c]);
+            m = (v == v && v > m) ? v : m;
+        }
     }
-    if (m > 0.f) atomicMax(out + c, __float_as_uint(m));
+    red[g][c] = m;
+    __syncthreads();
+    if (threadIdx.x < 16 && threadIdx.x < k) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t = red[q][threadIdx.x] > t ? red[q][threadIdx.x] : t;
+        if (t > 0.f) atomicMax(out + threadIdx.x, __float_as_uint(t));
+    }
 }
 // info[16 + c] <- 2^eb(c) (V is scaled by it), info[32 + c] <- 2^-(ea + eb(c)) (the unscaling)
 __global__ void h2_scale_kernel(unsigned* __restrict__ info, int ea) {
@@ -1082,7 +1091,7 @@ static int symm_matmat_h2_impl(const float* Kp, int64_t n, int64_t first, int64_
     frexp(kmax, &ex);
     const int ea = 14 - ex;  // stored entries <= kmax < 2^ex: scaled below 2^14
     if (hipMemsetAsync(info, 0, 256, st) != hipSuccess) return launch_status("rk_symm_matmat_f16x2(memset)");
-    hipLaunchKernelGGL(h2_absmax_kernel, dim3(1024), dim3(256), 0, st, V, n, (int)k, ldv, info);
+    hipLaunchKernelGGL(h2_absmax_kernel, dim3(256), dim3(256), 0, st, V, n, (int)k, ldv, info);
     hipLaunchKernelGGL(h2_scale_kernel, dim3(1), dim3(64), 0, st, info, ea);
     hipLaunchKernelGGL(h2_split_v_kernel, dim3((unsigned)ceil_div((npad / 8) * SMK, 256)), dim3(256), 0, st, V, n, npad,
                        (int)k, ldv, info, Vt);
