@@ -238,15 +238,40 @@ def test_fullsize_packed_symmetric_product(be, full_problem):
     assert float((Yw.double() - lin).norm() / lin.norm()) < 2e-5
     want_w = cbind.kernel_matmat("rbf", X[rows], X, 1.0, Wd.cpu())
     assert float((Yw[rows.to(DEV)].cpu() - want_w).norm() / want_w.norm()) < 2e-5
-    del Kp, Ku, free, Yw, Wd
+    # the same 10 columns through the float16-split kernel on the 16-bit matrix cores (what the operator calls:
+    # it knows the bound on its entries), "+ reg V" included: oracle rows, linearity, bitwise reproducibility
+    Yh = be.symm_matmat(Kp, n, Wd, diag_shift=reg, kmax=1.0)
+    assert torch.equal(Yh, be.symm_matmat(Kp, n, Wd, diag_shift=reg, kmax=1.0))
+    errh = (Yh[rows.to(DEV)].cpu() - (want_w + reg * Wd[rows.to(DEV)].cpu())).norm(dim=1) / want_w.norm(dim=1)
+    assert float(errh.max()) < 2e-5, errh
+    assert float((Yh.double() - (lin + reg * Wd.double())).norm() / lin.norm()) < 2e-5
+    # the sketch product from the same strips (rk_symm_gemm, 96 columns: two column tiles of 128 would be 256):
+    # sampled rows of the C oracle, the first 10 columns against the strip products, reproducibility
+    Om = torch.cat([Wd, torch.randn(n, 86, generator=torch.Generator().manual_seed(10)).to(DEV) / 86**0.5], dim=1)
+    Yg = be.symm_gemm(Kp, n, Om, kmax=1.0)
+    assert torch.equal(Yg, be.symm_gemm(Kp, n, Om, kmax=1.0))
+    # (float64 oracle rows: the float32 C product carries ~1e-5 itself over 200 000 sequential terms)
+    want_g = cbind.kernel_matmat("rbf", X[rows[:4]].double(), X.double(), 1.0, Om.cpu().double())
+    errg = float((Yg[rows[:4].to(DEV)].cpu().double() - want_g).norm() / want_g.norm())
+    assert errg < 1e-5, errg
+    assert float((Yg[:, :10].double() - lin).norm() / lin.norm()) < 2e-5
+    del Kp, Ku, free, Yw, Wd, Yh
     torch.cuda.empty_cache()
-    # the 8-rank layout: rank r owns strips r, r + 8, ...; the partial products add up
+    # the 8-rank layout: rank r owns strips r, r + 8, ...; the partial products add up (k = 1 register kernel,
+    # the float16-split kernel at k = 6, the sketch product)
     total = torch.zeros_like(y)
+    W6 = Om[:, :6].contiguous()
+    total6 = torch.zeros_like(W6)
+    totalg = torch.zeros_like(Yg)
     for r in range(8):
         Kr = be.sympack_materialize("rbf", Xd, 1.0, first=r, stride=8)
         total += be.symm_matmat(Kr, n, vd, first=r, stride=8)
+        total6 += be.symm_matmat(Kr, n, W6, first=r, stride=8, kmax=1.0)
+        totalg += be.symm_gemm(Kr, n, Om, kmax=1.0, first=r, stride=8)
         del Kr
     assert float((total - Kv).norm() / Kv.norm()) < 1e-5
+    assert float((total6.double() - Yg[:, :6].double()).norm() / Yg[:, :6].double().norm()) < 1e-5
+    assert float((totalg.double() - Yg.double()).norm() / Yg.double().norm()) < 1e-5
 
 
 def test_fullsize_lsqr_recovers_planted_solution():
