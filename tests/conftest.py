@@ -30,6 +30,19 @@ DTYPES = {"f32": torch.float32, "f64": torch.float64}
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (HIP kernels execute)")
+    # The host side of the tests (the oracle) gets as many threads as this process may actually use: a GPU box
+    # is a 16-CPU cgroup share of a 256-thread host, and torch / OpenMP pools sized for the whole host are only
+    # throttled (the oracle solves of the parity tests ran several times slower with 128 threads).
+    try:
+        from oracle import cbind
+
+        cpus = cbind.host_cpus()
+        if cpus < torch.get_num_threads():
+            torch.set_num_threads(cpus)
+        if os.path.exists(cbind.LIB_PATH) and cpus < cbind.num_threads():
+            cbind.set_num_threads(cpus)
+    except Exception:  # noqa: BLE001 - a tuning step only
+        pass
 
 
 def load_golden(name: str) -> dict:
