@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--r", type=int, nargs="+", default=[512, 100, 256])
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--fold", type=int, nargs="+", default=[16, 64, 8])
+    ap.add_argument("--stride", type=int, default=1,
+                    help="> 1: time rank 0's partial of a cyclic strip distribution over this many ranks (and stop)")
     ap.add_argument("--check-rows", type=int, default=2048)
     args = ap.parse_args()
     be = get_backend()
@@ -29,6 +31,23 @@ def main():
     n, d = args.n, args.d
     g = torch.Generator().manual_seed(0)
     X = (torch.randn(n, d, dtype=torch.float64, generator=g) / d**0.5).float().to(dev)
+    if args.stride > 1:
+        for first in (0, args.stride - 1):
+            Kp = be.sympack_materialize("rbf", X, 1.0, first=first, stride=args.stride)
+            for r in args.r:
+                Om = (torch.randn(n, r, generator=g) / r**0.5).to(dev)
+                be.symm_gemm(Kp, n, Om, first=first, stride=args.stride)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.reps):
+                    be.symm_gemm(Kp, n, Om, first=first, stride=args.stride)
+                e1.record()
+                torch.cuda.synchronize()
+                print(f"rank {first} of {args.stride}: r={r}: partial sketch product {e0.elapsed_time(e1) / args.reps:.2f} ms "
+                      f"({Kp.numel() * 4 / 1e9:.1f} GB of strips)", flush=True)
+            del Kp
+        return
     t0 = time.time()
     Kp = be.sympack_materialize("rbf", X, 1.0)
     torch.cuda.synchronize()
