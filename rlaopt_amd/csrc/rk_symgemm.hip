@@ -33,7 +33,7 @@
 // Per step and workgroup: the K tile is loaded to registers, scaled, split and written to LDS in operand
 // layout (row-major 64-byte rows, 16-byte chunks XOR-swizzled: conflict-free ds_read_b128 for the
 // 16-row x 4-chunk operand fetch); the V tile is a linear copy of a pre-split, pre-swizzled image written
-// once per call.  Two LDS buffers, loads two steps ahead in registers, one barrier per step.  Waves: 4 x 2
+// once per call.  Two LDS buffers, loads two and three steps ahead in two register sets, one barrier per step.  Waves: 4 x 2
 // (eight per workgroup, two per SIMD: one wave's staging and waits sit beside the other's matrix-core work -
 // with four waves, one per SIMD, the matrix cores were busy 39 % of the time), each 32 rows x TN / 2 columns
 // = 2 x NCB accumulator blocks of v_mfma_f32_16x16x32_{f16,bf16}.
@@ -221,7 +221,13 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
     // under round-robin placement (speed only) - and start together
     const int64_t grp = (int64_t)blockIdx.x / (8 * nct);
     const int64_t rem = (int64_t)blockIdx.x % (8 * nct);
-    const int64_t rb = grp * 8 + (rem & 7);
+    // (the slot inside a group of 8 row blocks is rotated by the group index: with cyclically dealt strips the row
+    // blocks whose own strip is local - the ones with the long transposed phase - are every (2 stride)-th pair; an
+    // un-rotated map put ALL of them on two of the eight XCDs at stride 8: 57 ms for an eighth of the work)
+    // Last row blocks first: with cyclically dealt strips a row block whose own strip is local walks 8 b transposed
+    // steps on top of its direct ones - the later the block, the longer its workgroup: longest first shortens the tail
+    // (one GPU: every workgroup does the same n / 32 steps and the order does not matter).
+    const int64_t rb = ((int64_t)gridDim.x / nct - 1) - (grp * 8 + (((rem & 7) + grp) & 7));
     const int64_t ct = rem >> 3;
     const int64_t i0 = rb * SG_TM;
     if (i0 >= L.n) return;  // (uniform, before any barrier)
@@ -263,25 +269,31 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
             }
     };
 
-    float araw[8];
-    sg_u4 braw[NBQ];
+    // two register sets: the loads of steps q + 2 and q + 3 are in flight while step q is computed (with one set -
+    // one step of cover - a rank's partial over cyclically dealt strips, where both operands come from HBM, ran at
+    // a quarter of the single-GPU rate)
+    struct Stage {
+        float a[8];
+        sg_u4 b[NBQ];
+    };
+    Stage sA, sB;
 
     // ---- loads of one step into registers ----------------------------------------------------------
-    auto load_b = [&](int64_t jstep) {
+    auto load_b = [&](int64_t jstep, Stage& st) {
         const sg_u4* src = reinterpret_cast<const sg_u4*>(img + ((jstep * nct + ct) * NS) * (int64_t)BBYTES);
 #pragma unroll
-        for (int q = 0; q < NBQ; ++q) braw[q] = src[tid + SG_THREADS * q];
+        for (int q = 0; q < NBQ; ++q) st.b[q] = src[tid + SG_THREADS * q];
     };
     // transposed step q: rows j = 32 q .. + 32 of strip b, columns ioff + (0 .. 127): lane <-> column,
     // thread group tid >> 7 <-> 8-row chunk
-    auto load_t = [&](int64_t q) {
+    auto load_t = [&](int64_t q, Stage& st) {
         const float* base = Kp + (L.row_offset(tb) + q * SG_KT + (tid >> 7) * 8) * W + ioff + (tid & 127);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) araw[e] = __builtin_nontemporal_load(base + (int64_t)e * W);
-        load_b(q);
+        for (int e = 0; e < 8; ++e) st.a[e] = __builtin_nontemporal_load(base + (int64_t)e * W);
+        load_b(q, st);
     };
     // direct step q: local strip t_min + q / 8, its columns 32 (q % 8) .. + 32, rows i0 .. i0 + 127
-    auto load_d = [&](int64_t q) {
+    auto load_d = [&](int64_t q, Stage& st) {
         const int64_t t = t_min + q / (W / SG_KT);
         const int kk = (int)(q % (W / SG_KT)) * SG_KT;
         const int64_t s = L.first + t * L.stride;
@@ -291,24 +303,24 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
             int64_t row = i0 + u * 64 + (tid >> 3);
             row = row < L.n ? row : L.n - 1;  // (rows past n: finite stand-ins, never stored)
             const sg_u4 v = __builtin_nontemporal_load(reinterpret_cast<const sg_u4*>(base + row * W));
-            araw[u * 4 + 0] = __uint_as_float(v.x); araw[u * 4 + 1] = __uint_as_float(v.y);
-            araw[u * 4 + 2] = __uint_as_float(v.z); araw[u * 4 + 3] = __uint_as_float(v.w);
+            st.a[u * 4 + 0] = __uint_as_float(v.x); st.a[u * 4 + 1] = __uint_as_float(v.y);
+            st.a[u * 4 + 2] = __uint_as_float(v.z); st.a[u * 4 + 3] = __uint_as_float(v.w);
         }
-        load_b(s * (W / SG_KT) + kk / SG_KT);
+        load_b(s * (W / SG_KT) + kk / SG_KT, st);
     };
     // ---- registers -> LDS (scale, split, operand layout) ------------------------------------------------
-    auto store_b = [&](int buf) {
+    auto store_b = [&](int buf, const Stage& st) {
         sg_u4* dst = reinterpret_cast<sg_u4*>(BL + buf * NS * BBYTES);
 #pragma unroll
-        for (int q = 0; q < NBQ; ++q) dst[tid + SG_THREADS * q] = braw[q];
+        for (int q = 0; q < NBQ; ++q) dst[tid + SG_THREADS * q] = st.b[q];
     };
-    auto store_t = [&](int buf) {
+    auto store_t = [&](int buf, const Stage& st) {
         unsigned char* al = AL + buf * NS * ABYTES;
         const int i = tid & 127, c = tid >> 7;
         unsigned pk[4][NS];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            F::split2(araw[2 * e] * (F::SCALED ? sa : 1.f), araw[2 * e + 1] * (F::SCALED ? sa : 1.f), pk[e]);
+            F::split2(st.a[2 * e] * (F::SCALED ? sa : 1.f), st.a[2 * e + 1] * (F::SCALED ? sa : 1.f), pk[e]);
         unsigned char* dst = al + i * SG_ROWB + (sg_swz(i, c) << 4);
 #pragma unroll
         for (int p = 0; p < NS; ++p) {
@@ -316,9 +328,9 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
             o.x = pk[0][p]; o.y = pk[1][p]; o.z = pk[2][p]; o.w = pk[3][p];
             *reinterpret_cast<sg_u4*>(dst + p * ABYTES) = o;
         }
-        store_b(buf);
+        store_b(buf, st);
     };
-    auto store_d = [&](int buf) {
+    auto store_d = [&](int buf, const Stage& st) {
         unsigned char* al = AL + buf * NS * ABYTES;
         const int c16 = tid & 7;
 #pragma unroll
@@ -327,7 +339,7 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
             unsigned pk[2][NS];
 #pragma unroll
             for (int e = 0; e < 2; ++e)
-                F::split2(araw[u * 4 + 2 * e] * (F::SCALED ? sa : 1.f), araw[u * 4 + 2 * e + 1] * (F::SCALED ? sa : 1.f), pk[e]);
+                F::split2(st.a[u * 4 + 2 * e] * (F::SCALED ? sa : 1.f), st.a[u * 4 + 2 * e + 1] * (F::SCALED ? sa : 1.f), pk[e]);
             unsigned char* dst = al + row * SG_ROWB + (sg_swz(row, c16 >> 1) << 4) + (c16 & 1) * 8;
 #pragma unroll
             for (int p = 0; p < NS; ++p) {
@@ -336,7 +348,7 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
                 *reinterpret_cast<sg_u2*>(dst + p * ABYTES) = o;
             }
         }
-        store_b(buf);
+        store_b(buf, st);
     };
     // ---- one step of matrix-core work out of LDS ----------------------------------------------------------
     const int a_off = (wr * 16 * SG_RB + lr) * SG_ROWB + (sg_swz(lr, lq) << 4);       // + rbk * 16 rows
@@ -366,36 +378,32 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
         }
     };
 
-    // ---- phase 1: transposed tiles ------------------------------------------------------------------------
-    if (nT > 0) {
-        load_t(0);
-        store_t(0);
-        load_t(nT > 1 ? 1 : 0);
+    // ---- the two phases: transposed tiles, then direct tiles (same pipeline, different loads / stores) ----------
+    auto run_phase = [&](auto load, auto store, int64_t nst) {
+        if (nst <= 0) return;
+        auto at = [&](int64_t q) { return q < nst ? q : nst - 1; };  // (past the end: the last step again, unused)
+        load(0, sA);
+        store(0, sA);
+        load(at(1), sA);
+        load(at(2), sB);
         __syncthreads();
-        for (int64_t q = 0; q < nT; ++q) {
-            const int buf = (int)(q & 1);
-            store_t(buf ^ 1);                          // step q + 1 (past the end: the last one again, unused)
-            load_t(q + 2 < nT ? q + 2 : nT - 1);
-            compute(buf);
+        for (int64_t q = 0; q < nst; q += 2) {
+            store(1, sA);          // step q + 1
+            load(at(q + 3), sA);
+            compute(0);
             if (((int)q & fold_mask) == fold_mask) fold();
             __syncthreads();
+            if (q + 1 < nst) {
+                store(0, sB);      // step q + 2
+                load(at(q + 4), sB);
+                compute(1);
+                if (((int)(q + 1) & fold_mask) == fold_mask) fold();
+                __syncthreads();
+            }
         }
-    }
-    // ---- phase 2: direct tiles ------------------------------------------------------------------------------
-    if (nD > 0) {
-        load_d(0);
-        store_d(0);
-        load_d(nD > 1 ? 1 : 0);
-        __syncthreads();
-        for (int64_t q = 0; q < nD; ++q) {
-            const int buf = (int)(q & 1);
-            store_d(buf ^ 1);
-            load_d(q + 2 < nD ? q + 2 : nD - 1);
-            compute(buf);
-            if (((int)q & fold_mask) == fold_mask) fold();
-            __syncthreads();
-        }
-    }
+    };
+    run_phase(load_t, store_t, nT);
+    run_phase(load_d, store_d, nD);
     // ---- epilogue: element v of a lane is Y[row 4 (lane / 16) + v][column lane % 16] of its block -----------
     const int64_t kpad = nct * TN;
 #pragma unroll
