@@ -36,7 +36,9 @@
 // once per call.  Two LDS buffers, loads two and three steps ahead in two register sets, one barrier per step.  Waves: 4 x 2
 // (eight per workgroup, two per SIMD: one wave's staging and waits sit beside the other's matrix-core work -
 // with four waves, one per SIMD, the matrix cores were busy 39 % of the time), each 32 rows x TN / 2 columns
-// = 2 x NCB accumulator blocks of v_mfma_f32_16x16x32_{f16,bf16}.
+// = 2 x NCB accumulator blocks of v_mfma_f32_16x16x32_{f16,bf16}.  Measured and not kept (A/B on one box, 121.0 ms):
+// s_setprio 1 for waves 4 - 7 (120.8 ms), sched_group_barrier interleaving of operand reads and matrix-core
+// instructions (122.2 ms).
 #include <atomic>
 #include <stdlib.h>
 
