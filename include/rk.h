@@ -300,6 +300,17 @@ int rk_gram_tn(int dtype, const void* A, int64_t lda, const void* B, int64_t ldb
                int64_t rows, int64_t m, int64_t n, double* C, int64_t ldc,
                void* ws, size_t ws_bytes, void* stream);
 
+/* Nystrom shifted-inverse apply  [a9]:  Y (n x k) = (X - U (M (U^T X))) / rho  for the factors of
+ * rlaopt/preconditioners/nystrom.py:112-132 - both reference branches reduce to this form: float64
+ * M = diag(S / (S + rho)) (mdiag != 0: M is a length-r vector), float32 M = (rho diag(1 / S) + U^T U)^-1
+ * (r x r row-major float64) - in three launches: U^T X (float64 accumulation), the r x r step, the rank-r
+ * update fused with the scaling.  U: n x r of `dtype`; 1 <= k <= 16.  (Row-sharded U: the host composes
+ * rk_matmat_skinny_t + all-reduce + rk_matmat_skinny instead.) */
+size_t rk_nystrom_inv_apply_ws_bytes(int dtype, int64_t n, int64_t r, int64_t k);
+int rk_nystrom_inv_apply(int dtype, const void* U, int64_t n, int64_t r, int64_t ldu, const double* M, int mdiag,
+                         double rho, const void* X, int64_t k, int64_t ldx, void* Y, int64_t ldy, void* ws,
+                         size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Block-PCG vector updates  [a11]   (all n x k row-major, k <= 16, coefficient
  * matrices k x k FLOAT64 on the device so that the loop never synchronises the host)

@@ -1118,6 +1118,31 @@ pi_factor_kernel(const double* __restrict__ M, int mdiag, const double* __restri
     }
 }
 
+// the same for k right-hand sides: t (r x k, row-major, T) = M c,  c (r x k, row-major float64)
+template <typename T>
+__global__ void __launch_bounds__(256)
+nys_factor_kernel(const double* __restrict__ M, int mdiag, const double* __restrict__ c, int r, int k,
+                  T* __restrict__ t) {
+    // 16 rows of M per workgroup (16 lanes per row): r = 512 spreads its 2 MB over 32 CUs
+    if (mdiag) {
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < r * k; e += gridDim.x * 256) t[e] = (T)(M[e / k] * c[e]);
+        return;
+    }
+    const int l = threadIdx.x & 15;
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (i >= r) return;  // (whole 16-lane rows leave together)
+    const double* row = M + (int64_t)i * r;
+    for (int j = 0; j < k; ++j) {
+        double s = 0.0;
+        for (int q = l; q < r; q += 16) s += row[q] * c[(int64_t)q * k + j];
+        s += dpp_fetch<0xB1, 0xF>(s);
+        s += dpp_fetch<0x4E, 0xF>(s);
+        s += dpp_fetch<0x141, 0xF>(s);
+        s += dpp_fetch<0x140, 0xF>(s);
+        if (l == 0) t[(int64_t)i * k + j] = (T)s;
+    }
+}
+
 // block-wide sum of a double (1024 threads), result in every thread
 __device__ __forceinline__ double pi_block_sum(double x, double* red) {
     x = wave_total_lane63(x);
@@ -1241,6 +1266,45 @@ static int power_iteration_impl(int dtype, const T* K, int64_t m, int64_t ldk, d
         rc = launch_status("rk_power_iteration(update)");
     }
     return rc;
+}
+
+struct NysPlan {
+    size_t off_c, off_t, off_nn, nn_bytes, off_tt, tt_bytes, total;
+};
+static NysPlan plan_nys(int dtype, int64_t n, int64_t r, int64_t k) {
+    const size_t es = dtype == RK_F32 ? 4 : 8;
+    NysPlan p;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += round_up((int64_t)(bytes ? bytes : 1), 256); return at; };
+    p.off_c = take((size_t)r * k * sizeof(double));
+    p.off_t = take((size_t)r * k * es);
+    const NNPlan a = plan_nn(dtype, n, r, k);
+    p.nn_bytes = a.S > 1 ? (size_t)a.S * n * k * es : 0;
+    p.off_nn = take(p.nn_bytes);
+    p.tt_bytes = (size_t)plan_t(dtype, n, r).S * r * k * es;
+    p.off_tt = take(p.tt_bytes);
+    p.total = o;
+    return p;
+}
+
+template <typename T>
+static int nystrom_inv_apply_impl(int dtype, const T* U, int64_t n, int64_t r, int64_t ldu, const double* M, int mdiag,
+                                  double rho, const T* X, int64_t k, int64_t ldx, T* Y, int64_t ldy, void* ws,
+                                  hipStream_t st) {
+    const NysPlan p = plan_nys(dtype, n, r, k);
+    char* base = static_cast<char*>(ws);
+    double* c = reinterpret_cast<double*>(base + p.off_c);
+    T* t = reinterpret_cast<T*>(base + p.off_t);
+    // c = U^T X (float64), t = M c, Y = (X - U t) / rho
+    int rc = matmat_skinny_t_impl<T>(U, n, r, ldu, X, k, ldx, 1.0, 0.0, nullptr, k, c, k, 1, base + p.off_tt, p.tt_bytes,
+                                     st, dtype);
+    if (rc != RK_OK) return rc;
+    hipLaunchKernelGGL((nys_factor_kernel<T>), dim3((unsigned)ceil_div(r, 16)), dim3(256), 0, st, M, mdiag, c, (int)r, (int)k, t);
+    rc = launch_status("rk_nystrom_inv_apply(factor)");
+    if (rc != RK_OK) return rc;
+    const double inv_rho = 1.0 / rho;
+    return matmat_skinny_impl<T>(U, n, r, ldu, t, k, k, -inv_rho, inv_rho, X, ldx, 0.0, 0, Y, ldy,
+                                 p.nn_bytes ? base + p.off_nn : nullptr, p.nn_bytes, st, dtype);
 }
 
 }  // namespace rk
@@ -1652,4 +1716,30 @@ extern "C" int rk_randn(int dtype, void* out, int64_t rows, int64_t cols, int64_
         hipLaunchKernelGGL((randn_kernel<double>), grid, dim3(256), 0, st, (double*)out, rows, cols,
                            ld, seed, offset, scale);
     return launch_status("rk_randn");
+}
+
+extern "C" size_t rk_nystrom_inv_apply_ws_bytes(int dtype, int64_t n, int64_t r, int64_t k) {
+    if (n <= 0 || r <= 0 || k <= 0 || k > 16 || r > 4096) return 0;
+    return plan_nys(dtype, n, r, k).total;
+}
+
+extern "C" int rk_nystrom_inv_apply(int dtype, const void* U, int64_t n, int64_t r, int64_t ldu, const double* M,
+                                    int mdiag, double rho, const void* X, int64_t k, int64_t ldx, void* Y, int64_t ldy,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    clear_error();
+    RK_REQUIRE(dtype == RK_F32 || dtype == RK_F64, "rk_nystrom_inv_apply: bad dtype %d", dtype);
+    RK_REQUIRE(U && M && X && Y, "rk_nystrom_inv_apply: null pointer");
+    RK_REQUIRE(n > 0 && r > 0 && r <= 4096 && k >= 1 && k <= 16 && ldu >= r && ldx >= k && ldy >= k && rho > 0.0,
+               "rk_nystrom_inv_apply: bad sizes (n=%lld r=%lld k=%lld rho=%g)", (long long)n, (long long)r, (long long)k, rho);
+    const size_t need = plan_nys(dtype, n, r, k).total;
+    if (ws == nullptr || ws_bytes < need) {
+        set_error("rk_nystrom_inv_apply: workspace %zu B < required %zu B", ws_bytes, need);
+        return RK_ERR_WORKSPACE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == RK_F32)
+        return nystrom_inv_apply_impl<float>(dtype, (const float*)U, n, r, ldu, M, mdiag, rho, (const float*)X, k, ldx,
+                                             (float*)Y, ldy, ws, st);
+    return nystrom_inv_apply_impl<double>(dtype, (const double*)U, n, r, ldu, M, mdiag, rho, (const double*)X, k, ldx,
+                                          (double*)Y, ldy, ws, st);
 }

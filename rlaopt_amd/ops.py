@@ -516,6 +516,24 @@ class HipBackend:
         _lib.check(rc, "rk_spmd_pack")
         return out
 
+    def nystrom_inv_apply(self, U, M, rho, X):
+        """(X - U (M (U^T X))) / rho in three launches (``rk_nystrom_inv_apply``); M: r x r or length-r float64."""
+        dev = _req(U, M, X)
+        X2, squeeze = _as2d(X)
+        if X2.dtype != U.dtype or M.dtype != torch.float64 or X2.shape[0] != U.shape[0]:
+            raise ValueError("nystrom_inv_apply: X of U's dtype and row count, M float64")
+        U2, ldu = _rowmajor(U)
+        X2, ldx = _rowmajor(X2)
+        M = M.contiguous()
+        n, r = U2.shape
+        k = X2.shape[1]
+        out = torch.empty((n, k), dtype=U.dtype, device=dev)
+        ws, wsn = self._workspace(dev, self._lib.rk_nystrom_inv_apply_ws_bytes(_dt(U2), n, r, k))
+        rc = self._lib.rk_nystrom_inv_apply(_dt(U2), _ptr(U2), n, r, ldu, _ptr(M), int(M.ndim == 1), float(rho),
+                                            _ptr(X2), k, ldx, _ptr(out), k, _ptr(ws), wsn, _stream(dev))
+        _lib.check(rc, "rk_nystrom_inv_apply")
+        return out[:, 0] if squeeze else out
+
     # -- block PCG pieces --------------------------------------------------------------
     def pcg_update_wr(self, W, R, P, AP, alpha):
         dev = _req(W, R, P, AP, alpha)

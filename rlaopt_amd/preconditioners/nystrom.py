@@ -418,6 +418,10 @@ class Nystrom(Preconditioner):
         be = get_backend()
         X = x[:, None] if unsqueeze else x
         M = self._apply_factor()
+        if (not self._sharded and hasattr(be, "nystrom_inv_apply") and X.shape[1] <= 16 and X.is_cuda
+                and M.dtype == torch.float64):
+            out = be.nystrom_inv_apply(self.U, M, self._rho_now(), X)  # three launches, no host-side glue
+            return out[:, 0] if unsqueeze else out
         t = self._project(X, out_f64=True)  # r x k, float64
         t = be.matmat(M, t) if M.ndim == 2 else t * M[:, None]
         inv_rho = 1.0 / self._rho_now()

@@ -934,3 +934,29 @@ def test_symm_matmat_f16x2_matrix_core_strip_product(be, n, k, first, stride):
     assert float(err.max()) < 3e-6, (float(err.max()), int(err.argmax()))
     if first:
         assert float(parts[first].abs().max()) > 0
+
+
+@pytest.mark.parametrize("n,r,k", [(1000, 32, 1), (5000, 100, 10), (777, 17, 16), (64, 5, 3)])
+def test_nystrom_inv_apply_composite(be, prec, n, r, k):
+    """rk_nystrom_inv_apply: (X - U (M (U^T X))) / rho in three launches, with the dense r x r factor of the
+    float32 branch and the diagonal factor of the float64 branch (nystrom.py:112-132), 1-D and strided inputs."""
+    dt = DTYPES[prec]
+    g = torch.Generator().manual_seed(n + r)
+    U = torch.linalg.qr(torch.randn(n, r, dtype=torch.float64, generator=g))[0].to(dt)
+    X = torch.randn(n, k, dtype=dt, generator=g)
+    A = torch.randn(r, r, dtype=torch.float64, generator=g)
+    M = A @ A.T / r + torch.eye(r, dtype=torch.float64)
+    S = torch.rand(r, dtype=torch.float64, generator=g) + 0.1
+    rho = 0.37
+    Ud, Xd = U.to(dev()), X.to(dev())
+    lim = LIM[dt] * 5
+    want = (X.double() - U.double() @ (M @ (U.double().T @ X.double()))) / rho
+    assert rel_err(be.nystrom_inv_apply(Ud, M.to(dev()), rho, Xd).cpu(), want) < lim
+    Md = S / (S + rho)
+    want = (X.double() - U.double() @ (Md[:, None] * (U.double().T @ X.double()))) / rho
+    assert rel_err(be.nystrom_inv_apply(Ud, Md.to(dev()), rho, Xd).cpu(), want) < lim
+    got = be.nystrom_inv_apply(Ud, Md.to(dev()), rho, Xd[:, 0].contiguous())
+    assert got.shape == (n,) and rel_err(got.cpu(), want[:, 0]) < lim
+    wide = torch.randn(n, k + 2, dtype=dt, generator=g).to(dev())
+    want = (wide[:, 1 : 1 + k].cpu().double() - U.double() @ (M @ (U.double().T @ wide[:, 1 : 1 + k].cpu().double()))) / rho
+    assert rel_err(be.nystrom_inv_apply(Ud, M.to(dev()), rho, wide[:, 1 : 1 + k]).cpu(), want) < lim
