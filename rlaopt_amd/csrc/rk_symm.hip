@@ -762,19 +762,25 @@ symm_strip_h2_kernel(const float* __restrict__ Kp, SymLayout L, const unsigned s
             for (int v = 0; v < 4; ++v) { ccol[cb][v] = 0.f; ctot[cb][v] = 0.f; }
 
         float4 preA[RPW], preB[RPW];
-        h2_u4 viA[2], viB[2];
-        auto load_tile = [&](int tl, float4 (&pre)[RPW], h2_u4 (&vi)[2]) {
+        h2_u2 viA, viB;
+        // V of the tile's rows (B operand of the column part: 2 pieces x 16 rhs x 32 rows = 2 KiB per tile): ONE 8-byte
+        // load per thread (piece tid >> 7, rhs (tid >> 3) & 15, rows 4 (tid & 7) .. + 4), parked in the 32 padding bytes
+        // of the image rows (h2_off uses bytes 0 .. 511 of a 544-byte row) - each wave loading all of it from global
+        // was 8 KiB of L2 / Infinity-Cache reads per 32 KiB tile (PMC: fetches 1.11 x the packed bytes)
+        const unsigned short* vsrc = Vt + ((int64_t)(tid >> 7) * SMK + ((tid >> 3) & 15)) * npad + 4 * (tid & 7);
+        const int vch = 4 * ((tid >> 3) & 15) + ((tid & 7) >> 1);  // 16-byte chunk (rhs, 8-row group) this thread half-fills
+        const int vi_st = (tid >> 7) * H2_PIECE + (vch >> 1) * H2_ROWB + 512 + (vch & 1) * 16 + (tid & 1) * 8;
+        const int vi_ld = ((4 * lr + lq) >> 1) * H2_ROWB + 512 + ((4 * lr + lq) & 1) * 16;  // chunk (rhs lr, rows 8 lq .. + 8)
+        auto load_tile = [&](int tl, float4 (&pre)[RPW], h2_u2& vi) {
             const int64_t r0 = item_lo + (int64_t)(tl < ntile ? tl : ntile - 1) * TR;
 #pragma unroll
             for (int u = 0; u < RPW; ++u) {
                 const int64_t i = r0 + wave + 4 * u;
                 pre[u] = load_stream_at<float4>(base + (i < nrows ? i : nrows - 1) * W, (unsigned)lane * 16u);
             }
-            // V of the tile's rows (B operand of the column part): rows r0 + 8 lq .. + 8 of rhs lr (r0 + 32 <= npad)
-            vi[0] = *reinterpret_cast<const h2_u4*>(Vh + (int64_t)lr * npad + r0 + 8 * lq);
-            vi[1] = *reinterpret_cast<const h2_u4*>(Vm + (int64_t)lr * npad + r0 + 8 * lq);
+            vi = *reinterpret_cast<const h2_u2*>(vsrc + r0);  // (r0 + 32 <= npad)
         };
-        auto store_tile = [&](int buf, int tl, const float4 (&pre)[RPW]) {
+        auto store_tile = [&](int buf, int tl, const float4 (&pre)[RPW], const h2_u2& vi) {
             unsigned char* tb = TB + buf * 2 * H2_PIECE;
             const int64_t r0 = item_lo + (int64_t)(tl < ntile ? tl : ntile - 1) * TR;
 #pragma unroll
@@ -789,6 +795,7 @@ symm_strip_h2_kernel(const float* __restrict__ Kp, SymLayout L, const unsigned s
                 *reinterpret_cast<h2_u2*>(dst) = h;
                 *reinterpret_cast<h2_u2*>(dst + H2_PIECE) = mm;
             }
+            *reinterpret_cast<h2_u2*>(tb + vi_st) = vi;
         };
         auto flush_rows = [&](int buf, int tl) {  // add the two column halves, store to the row table
             const float* rp = RP + buf * 2 * TR * SMK;
@@ -801,7 +808,7 @@ symm_strip_h2_kernel(const float* __restrict__ Kp, SymLayout L, const unsigned s
                 if (r < live && c < ktab) __builtin_nontemporal_store(sum, &pr[r * ktab + c]);
             }
         };
-        auto compute = [&](int buf, int tl, const h2_u4 (&vi)[2]) {
+        auto compute = [&](int buf, int tl) {
             if (tl > 0) flush_rows(buf ^ 1, tl - 1);  // (RP[buf ^ 1] was completed before the last barrier)
             const unsigned char* tb = TB + buf * 2 * H2_PIECE;
             // ---- row part: A = rows 16 rb + lr, columns 128 cs + 32 s + 8 lq .. + 8 -----------------------
@@ -821,6 +828,9 @@ symm_strip_h2_kernel(const float* __restrict__ Kp, SymLayout L, const unsigned s
             // ---- column part (rows above the diagonal block only; tile-uniform): A = T^T through the
             // transposing read: columns 64 wave + 16 cb + (0 .. 15), rows 8 lq .. 8 lq + 7 ---------------------
             if (item_lo + (int64_t)tl * TR < diag_lo) {
+                h2_u4 vi[2];
+                vi[0] = *reinterpret_cast<const h2_u4*>(tb + vi_ld);
+                vi[1] = *reinterpret_cast<const h2_u4*>(tb + vi_ld + H2_PIECE);
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
                     h2_u4 a[2];
@@ -847,22 +857,19 @@ symm_strip_h2_kernel(const float* __restrict__ Kp, SymLayout L, const unsigned s
         };
 
         load_tile(0, preA, viA);
-        store_tile(0, 0, preA);
-        h2_u4 vi0[2] = {viA[0], viA[1]};  // V rows of the tile being computed travel one stage behind the loads
+        store_tile(0, 0, preA, viA);
         load_tile(1, preA, viA);
         load_tile(2, preB, viB);
         __syncthreads();
         for (int tl = 0; tl < ntile; tl += 2) {
-            store_tile(1, tl + 1, preA);
-            h2_u4 vi1[2] = {viA[0], viA[1]};
+            store_tile(1, tl + 1, preA, viA);
             load_tile(tl + 3, preA, viA);
-            compute(0, tl, vi0);
+            compute(0, tl);
             __syncthreads();  // tile tl + 1 staged, RP[0] complete, everyone done with TB[0]
             if (tl + 1 < ntile) {
-                store_tile(0, tl + 2, preB);
-                vi0[0] = viB[0]; vi0[1] = viB[1];
+                store_tile(0, tl + 2, preB, viB);
                 load_tile(tl + 4, preB, viB);
-                compute(1, tl + 1, vi1);
+                compute(1, tl + 1);
                 __syncthreads();
             }
         }
