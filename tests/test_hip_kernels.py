@@ -804,7 +804,8 @@ def test_kernel_matmat_keeps_the_x2_image_between_calls(be, monkeypatch, kind, d
 
 
 @pytest.mark.parametrize("n,k,first,stride", [(1000, 40, 0, 1), (2304, 100, 0, 1), (3000, 256, 0, 1), (5000, 512, 0, 1),
-                                             (4100, 130, 1, 3), (2600, 64, 0, 2), (2600, 64, 1, 2), (700, 17, 0, 1)])
+                                             (4100, 130, 1, 3), (2600, 64, 0, 2), (2600, 64, 1, 2), (700, 17, 0, 1),
+                                             (1500, 600, 0, 1), (1100, 1024, 0, 1), (2100, 700, 2, 5), (90, 33, 0, 1)])
 @pytest.mark.parametrize("split", ["f16x2", "bf16x3"])
 def test_symm_gemm_wide_product_from_the_packed_strips(be, monkeypatch, n, k, first, stride, split):
     """rk_symm_gemm: Y = K V for many columns straight from the float32 packed triangle (both piece formats),
