@@ -443,6 +443,10 @@ def main():
                 "history": [float(log64[i]["metrics"]["internal_metrics"]["rel_res"][0]) for i in sorted(log64)],
                 "wall_s_with_setup": round(t_all, 3),
                 "logger_cum_time_s": round(log64[last]["cum_time"], 3) if "cum_time" in log64[last] else None,
+                # iterations/s of the loop itself: the logger's device-synchronised clock between the first and the
+                # last logged iteration (it excludes the residual evaluations, like the reference's logger)
+                "iters_per_s": (last / (log64[last]["cum_time"] - log64[0]["cum_time"])
+                                if last > 0 and log64[last]["cum_time"] > log64[0]["cum_time"] else None),
                 "storage": A64.storage_mode,
             }
             del Om64, W64, sys64
