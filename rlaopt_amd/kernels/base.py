@@ -350,6 +350,15 @@ class _KernelLinOp(TwoSidedLinOp, ScaleMixin):
             return self._sym_matmat(X, diag_shift=shift)
         return self._block.matmat(X, diag_shift=shift, row0=0)
 
+    def _rk_columns(self, J: torch.Tensor) -> torch.Tensor:
+        """K[:, J] as a dense n1 x |J| block, written directly from the closed form (n1 |J| pair evaluations):
+        what a column-sampling sketch's ``A @ Omega`` is (sketches.ColSample)."""
+        return get_backend().kernel_materialize(
+            self._kind, self._A1, self._A2, self._kernel_config.lengthscale, scale=self._scaling,
+            idx2=J.to(self.device))
+
+    _rk_local_columns = _rk_columns
+
     def _get_kernel_linop(self, idx1=None, idx2=None) -> LinOp:
         """Matrix-free K(A1[idx1], A2[idx2]) (base.py:104-128); scaling applied once."""
         be, cfg = get_backend(), self._kernel_config
@@ -603,6 +612,25 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
         if isinstance(shard, _KernelShard):
             return shard._block.matmat(X_full.to(shard.device), diag_shift=diag_shift, row0=lo)
         return shard @ X_full  # raises for use_full_kernel=False
+
+    def _rk_local_columns(self, J: torch.Tensor) -> torch.Tensor:
+        """K[rows_i, J] for this rank's rows (one rank per GPU) or every row (one process): dense, written
+        directly from the closed form - the column-sampling sketch's image needs no product and no collective."""
+        be = get_backend()
+        if self._spmd:
+            lo, hi = self.row_range
+            dev = self.local_device
+        else:
+            lo, hi = 0, self.shape[0]
+            dev = self._shard_devices[0]
+        cfg = self._kernel_config_devices[dev]
+        A1r = self._A1[lo:hi].to(dev)
+        A2d = A1r if (lo, hi) == (0, self.shape[0]) and _same_points(self._A1, self._A2) else self._A2.to(dev)
+        return be.kernel_materialize(self._kind, A1r, A2d, cfg.lengthscale, scale=self._scaling, idx2=J.to(dev))
+
+    def _rk_columns(self, J: torch.Tensor) -> torch.Tensor:
+        Y = self._rk_local_columns(J)
+        return _dist.all_gather_rows(Y, self.shape[0], self._group) if self._spmd else Y
 
     def _rk_shifted_matmat(self, X, shift):
         if self._spmd or len(self._A) != 1:

@@ -113,9 +113,20 @@ class Nystrom(Preconditioner):
                 sk = get_sketch(self.config.sketch, "right", rank_r, A.shape[1], dtype=A.dtype, device=device)
         else:
             sk = get_sketch(self.config.sketch, "right", rank_r, A.shape[1], dtype=A.dtype, device=device)
+        lo, hi = A.row_range if self._sharded else (0, A.shape[0])
+        Ycols = sk.columns_of(A, local=self._sharded) if hasattr(sk, "columns_of") else None
+        if Ycols is not None:
+            # column-sampling sketch: Y = scaled columns of A (no product), Omega^T Y = scaled rows J of Y
+            Y = Ycols.to(device)
+            both = torch.stack([sk.rows_of(Y, lo, hi), be.gram_tn(Y, Y)])
+            if self._sharded:
+                _dist.all_reduce_sum(both, self._group)
+            if before_host_wait is not None:
+                before_host_wait()
+            host = both.cpu()
+            return Y, host[0], host[1], None
         Om = sk.Omega_mat
         if self._sharded:
-            lo, hi = A.row_range
             Y = A.local_matmat(Om)  # rows [lo, hi) of A @ Omega, never gathered
             Om_rows = Om[lo:hi]
         else:

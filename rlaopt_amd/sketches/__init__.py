@@ -10,6 +10,11 @@ Differences from the reference, by design:
 * The orthonormal sketch is CholeskyQR2 on the device (two f64-accumulated Gram products +
   two tall GEMMs) instead of a Householder QR; the result spans the same space and differs
   from LAPACK's Q only by column signs, to which the Nystrom approximation is invariant.
+* ``"colsample"`` is this build's addition (BASELINE.json's north_star names column-sampling sketches; the
+  reference's factory knows gauss / ortho / sparse only, factory.py:25-59): Omega = sqrt(d / s) [e_j1 ... e_js]
+  with s distinct uniform indices (``rk_sample_distinct``).  A Omega is then s COLUMNS of A - for a kernel
+  operator one ``rk_kernel_materialize(idx2=J)`` call, n s pair evaluations instead of an n x n x s product -
+  and Omega^T Y a gather of s rows; the dense matrix is only built on demand.
 * ``inject(...)`` feeds externally generated matrices (parity tests / benchmarks use the
   reference's own CPU draws, SURVEY.md section 7 "RNG parity").
 """
@@ -51,16 +56,17 @@ class _SketchMode(Enum):
     GAUSS = "gauss"
     ORTHO = "ortho"
     SPARSE = "sparse"
+    COLSAMPLE = "colsample"
 
     @classmethod
     def _from_str(cls, value, param_name):
         if isinstance(value, cls):
             return value
-        if isinstance(value, str) and value.lower() in ("gauss", "ortho", "sparse"):
+        if isinstance(value, str) and value.lower() in ("gauss", "ortho", "sparse", "colsample"):
             return cls(value.lower())
         raise ValueError(
-            f"Invalid value for {param_name}: {value}. Expected 'gauss', 'ortho', 'sparse', "
-            "_SketchMode.GAUSS, _SketchMode.ORTHO, or _SketchMode.SPARSE."
+            f"Invalid value for {param_name}: {value}. Expected 'gauss', 'ortho', 'sparse', 'colsample', "
+            "_SketchMode.GAUSS, _SketchMode.ORTHO, _SketchMode.SPARSE, or _SketchMode.COLSAMPLE."
         )
 
 
@@ -244,10 +250,91 @@ class Sparse(Sketch):
         return super()._apply_left(x)
 
 
-SKETCH_MODE_TO_CLASS = {_SketchMode.GAUSS: Gauss, _SketchMode.ORTHO: Ortho, _SketchMode.SPARSE: Sparse}
+class ColSample(Sketch):
+    """Uniform column sampling without replacement: the (s, d) embedding has rows sqrt(d / s) e_j, j in J, |J| = s
+    distinct (the scale makes E[Omega^T Omega] = I like the other sketches; the Nystrom approximation does not
+    depend on it).  ``indices`` (int64, on the device) and ``col_scale`` describe it completely; products with it
+    are gathers:
+
+        A @ Omega   (mode 'right')  = col_scale * A[:, J]      - kernel operators: K(A1, A2[J]) written directly
+        Omega^T @ Y (mode 'right')  = col_scale * Y[J, :]
+        Omega @ A   (mode 'left')   = col_scale * A[J, :]      - the SkPre update
+
+    s > d is clipped to d (every column once).  An injected matrix is used as a dense sketch."""
+
+    def __init__(self, mode, sketch_size, matrix_dim, dtype, device):
+        self.indices, self.col_scale = None, 1.0
+        super().__init__(mode, sketch_size, matrix_dim, dtype, device)
+
+    def _generate_embedding(self):
+        be = get_backend()
+        s, d, dev = self.s, self.d, torch.device(self.device)
+        take = min(s, d)
+        seed, _offset = _draw_seed()
+        if dev.type == "cuda" and hasattr(be, "sample_distinct"):
+            J = be.sample_distinct(d, take, dev, seed)
+        else:  # host stand-in backends (CPU tests)
+            g = torch.Generator().manual_seed(seed)
+            J = torch.randperm(d, generator=g)[:take].to(dev)
+        if take < s:  # pad with repeats of the first draws: zero information, but the declared shape holds
+            J = torch.cat([J, J[: s - take]])
+        self.indices = J
+        self.col_scale = (d / s) ** 0.5
+        return None  # dense form on demand
+
+    def _densify(self):
+        Om = torch.zeros((self.s, self.d), dtype=self.dtype, device=self.device)
+        Om[torch.arange(self.s, device=self.device), self.indices] = self.col_scale
+        return Om.T.contiguous() if self.mode is _SketchSide.RIGHT else Om
+
+    def columns_of(self, A, local: bool = False):
+        """col_scale * A[:, J] (``local``: only the rows of this rank's shard) without forming Omega, or None when
+        A offers no column access (the caller then multiplies by the dense matrix)."""
+        if self.indices is None or self.mode is not _SketchSide.RIGHT:
+            return None
+        if isinstance(A, torch.Tensor):
+            return A[:, self.indices.to(A.device)] * self.col_scale
+        fn = getattr(A, "_rk_local_columns" if local else "_rk_columns", None)
+        if fn is None:
+            return None
+        Y = fn(self.indices)
+        return None if Y is None else Y * self.col_scale
+
+    def rows_of(self, Y, lo: int = 0, hi: int | None = None):
+        """Omega^T Y restricted to the rows [lo, hi) that ``Y`` holds (row p = col_scale * Y[J[p] - lo] when
+        lo <= J[p] < hi, else 0): the r x r Nystrom core, float64; per-rank partials add up."""
+        J = self.indices.to(Y.device)
+        hi = lo + Y.shape[0] if hi is None else hi
+        inside = (J >= lo) & (J < hi)
+        rows = Y[(J - lo).clamp(0, max(Y.shape[0] - 1, 0))].double() * self.col_scale
+        return rows * inside[:, None].to(rows.dtype)
+
+    def _apply_right(self, x):
+        if self.indices is not None and self.mode is _SketchSide.RIGHT:
+            Y = self.columns_of(x)
+            if Y is not None:
+                return Y
+        return super()._apply_right(x)
+
+    def _apply_left(self, x):
+        if (self.indices is not None and self.mode is _SketchSide.LEFT
+                and isinstance(x, torch.Tensor) and x.ndim == 2):
+            return x[self.indices.to(x.device)] * self.col_scale
+        return super()._apply_left(x)
+
+    def _apply_left_trans(self, x):
+        if (self.indices is not None and self.mode is _SketchSide.RIGHT
+                and isinstance(x, torch.Tensor) and x.ndim == 2):
+            return x[self.indices.to(x.device)] * self.col_scale
+        return super()._apply_left_trans(x)
+
+
+SKETCH_MODE_TO_CLASS = {_SketchMode.GAUSS: Gauss, _SketchMode.ORTHO: Ortho, _SketchMode.SPARSE: Sparse,
+                        _SketchMode.COLSAMPLE: ColSample}
 
 
 def get_sketch(name, mode, sketch_size, matrix_dim, dtype, device) -> Sketch:
-    """Factory (factory.py:25-59): name in {'gauss','ortho','sparse'}, mode in {'left','right'}."""
+    """Factory (factory.py:25-59): name in {'gauss','ortho','sparse'} (+ 'colsample', this build's addition),
+    mode in {'left','right'}."""
     cls = SKETCH_MODE_TO_CLASS[_SketchMode._from_str(name, "name")]
     return cls(mode, sketch_size, matrix_dim, dtype, device)
