@@ -362,6 +362,18 @@ def main():
     sync()
     t_pre_warm = time.time() - t0
     del Omd, _p2
+    # the same assembly with the column-sampling sketch (Y = K[:, J] written from the closed form: no n x n x r
+    # product at all); discarded - the timed iterations use the Gaussian preconditioner above
+    t_cs = []
+    for _ in range(2):
+        sync()
+        t0 = time.time()
+        _p3 = _Nystrom(NystromConfig(rank=r, rho=reg, sketch="colsample", damping_mode="adaptive"))
+        _p3._update(A, dev)
+        _p3._update_damping(baseline_rho=reg)
+        sync()
+        t_cs.append(time.time() - t0)
+    del _p3
 
     def one_step():
         solver._step()
@@ -579,6 +591,8 @@ def main():
             "setup_materialize_s": round(t_mat, 3),
             "setup_nystrom_s": round(t_pre, 3),
             "setup_nystrom_warm_s": round(t_pre_warm, 3),
+            "setup_nystrom_colsample_s": round(t_cs[0], 3),
+            "setup_nystrom_colsample_warm_s": round(t_cs[1], 3),
             "process_group": {"world_size_seen": td.get_world_size() if world > 1 else 1,
                               "backend": td.get_backend() if world > 1 else None, **wire},
             "rel_res_after_timed_steps": rel_now,

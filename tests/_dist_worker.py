@@ -182,6 +182,52 @@ def main():
                 torch.zeros_like(B), callback_freq=5)
         ressp = torch.linalg.norm(B - (Kd @ Wsp + reg * Wsp), dim=0) / torch.linalg.norm(B, dim=0)
         assert bool((ressp <= 1e-9).all()), ressp
+        # ---- column-sampling sketch on the sharded operator: every rank draws the same J, writes ITS rows of
+        # K[:, J] (no product, no collective), the core is the all-reduced row gather; same preconditioner as
+        # the oracle fed the dense Omega --------------------------------------------------------------------
+        from rlaopt_amd.preconditioners.nystrom import Nystrom
+
+        torch.manual_seed(2000 + rank)
+        skc = sketches.get_sketch("colsample", "right", r, n, dt, cpu)
+        Jsum = skc.indices.clone()
+        td.all_reduce(Jsum)
+        assert torch.equal(Jsum, skc.indices * size)
+        torch.testing.assert_close(skc.columns_of(A, local=True), Kd[lo:hi][:, skc.indices] * skc.col_scale, **tol)
+        torch.testing.assert_close(skc.columns_of(A), Kd[:, skc.indices] * skc.col_scale, **tol)
+        # the preconditioner's own draw, captured (the ranks share one seed stream: a second get_sketch call
+        # draws a new subset)
+        import rlaopt_amd.preconditioners.nystrom as nymod
+
+        seen = []
+        real_get = nymod.get_sketch
+        nymod.get_sketch = lambda *a, **k: seen.append(real_get(*a, **k)) or seen[-1]
+        try:
+            Pc = Nystrom(NystromConfig(rank=r, rho=reg, sketch="colsample"))
+            rdist.reset_wire_stats()
+            Pc._update(A, cpu)
+            Pc._update_damping(reg)
+        finally:
+            nymod.get_sketch = real_get
+        assert "all_gather" not in rdist.wire_stats["by_kind"], rdist.wire_stats  # nothing n-long moved
+        Omc = seen[0].Omega_mat
+        stc = on.build(Kd, Omc, reg)
+        on.update_damping(stc, reg, adaptive=True)
+        with sketches.inject(Omc):  # the dense route (products + collectives) on the same matrix
+            Pd = Nystrom(NystromConfig(rank=r, rho=reg, sketch="gauss"))
+            Pd._update(A, cpu)
+            Pd._update_damping(reg)
+        assert abs(Pc.config.rho - stc.rho) <= 1e-8 * abs(stc.rho) + 1e-12, (Pc.config.rho, Pd.config.rho, stc.rho)
+        assert abs(Pd.config.rho - stc.rho) <= 1e-8 * abs(stc.rho) + 1e-12
+        rloc = B[lo:hi]
+        want_inv = on.inverse_matmul(stc, B)[lo:hi]
+        torch.testing.assert_close(Pc._inv @ rloc if not Pc._sharded else Pc._inverse_matmul_with_gram(rloc)[0],
+                                   want_inv, rtol=1e-7, atol=1e-9)
+        Wcs, logcs = LinSys(A, B, reg=reg).solve(
+            PCGConfig(device=cpu, max_iters=200, atol=0.0, rtol=1e-9,
+                      precond_config=NystromConfig(rank=r, rho=reg, sketch="colsample")),
+            torch.zeros_like(B), callback_freq=5)
+        rescs = torch.linalg.norm(B - (Kd @ Wcs + reg * Wcs), dim=0) / torch.linalg.norm(B, dim=0)
+        assert bool((rescs <= 1e-9).all()), rescs
         # ---- SPMD sketch-and-project (distributed row / block oracles, replicated iterates) --------
         from oracle import sap as osap
         from rlaopt_amd.solvers import SAPAccelConfig, SAPConfig

@@ -590,3 +590,129 @@ def test_linsys_callback_and_log_layout(dev, prec):
     assert system.mask.dtype == torch.bool and not bool(system.mask.any())
     with pytest.raises(ValueError):
         system.solve(PCGConfig(device=dev), torch.zeros_like(B), log_in_wandb=True)
+
+
+# -- column-sampling sketch (north_star; no counterpart in the reference's factory: formula-pinned) ---------
+def test_colsample_sketch_is_scaled_distinct_columns(dev, prec):
+    """get_sketch('colsample'): s distinct uniform indices, Omega = sqrt(d / s) [e_j]; A @ Omega is the scaled
+    column block for a tensor and for a kernel operator (whose columns are written from the closed form: they
+    must equal the columns of the golden-pinned oracle kernel matrix), Omega^T Y the scaled row block."""
+    dt = DTYPES[prec]
+    g = torch.Generator().manual_seed(5)
+    n, d, s = 300, 5, 40
+    X = torch.randn(n, d, dtype=dt, generator=g)
+    K = ok.kernel_matrix("rbf", X, X, 1.3)
+    torch.manual_seed(21)
+    sk = sketches.get_sketch("colsample", "right", s, n, dtype=dt, device=dev)
+    J = sk.indices.cpu()
+    assert J.shape == (s,) and J.unique().numel() == s and int(J.min()) >= 0 and int(J.max()) < n
+    assert abs(sk.col_scale - (n / s) ** 0.5) < 1e-12
+    Om = sk.Omega_mat.cpu()
+    assert Om.shape == (n, s) and int((Om != 0).sum()) == s
+    torch.testing.assert_close(Om[J, torch.arange(s)], torch.full((s,), sk.col_scale, dtype=dt))
+    tol = TOL[dt]
+    Xd = X.to(dev)
+    A = RBFLinOp(Xd, Xd, KernelConfig(lengthscale=1.3))
+    Y = sk._apply_right(A)
+    assert Y.shape == (n, s) and Y.device.type == dev.type
+    torch.testing.assert_close(Y.cpu(), K[:, J] * sk.col_scale, **tol)
+    torch.testing.assert_close(sk._apply_right(K.to(dev)).cpu(), K @ Om, **tol)
+    torch.testing.assert_close(sk._apply_left_trans(Y).cpu(), Om.T @ Y.cpu(), **tol)
+    torch.testing.assert_close(sk.rows_of(Y).cpu().to(dt), Om.T @ Y.cpu(), **tol)
+    # 'left' orientation (SkPre): Omega is (s, d_rows), Omega @ M gathers rows
+    torch.manual_seed(22)
+    sl = sketches.get_sketch("colsample", "left", 16, n, dtype=dt, device=dev)
+    M = torch.randn(n, 7, dtype=dt, generator=g).to(dev)
+    torch.testing.assert_close(sl._apply_left(M).cpu(), sl.Omega_mat.cpu() @ M.cpu(), **tol)
+    # a different seed draws a different subset; the same seed the same one
+    torch.manual_seed(21)
+    again = sketches.get_sketch("colsample", "right", s, n, dtype=dt, device=dev).indices.cpu()
+    assert torch.equal(again, J)
+    torch.manual_seed(23)
+    other = sketches.get_sketch("colsample", "right", s, n, dtype=dt, device=dev).indices.cpu()
+    assert not torch.equal(other, J)
+    # more samples than columns: every column once, shape kept
+    torch.manual_seed(24)
+    full = sketches.get_sketch("colsample", "right", 12, 9, dtype=dt, device=dev)
+    assert full.indices.shape == (12,) and full.indices[:9].unique().numel() == 9
+
+
+@pytest.mark.parametrize("mode", ["adaptive", "non_adaptive"])
+@pytest.mark.parametrize("opkind", ["kernel", "tensor"])
+def test_nystrom_colsample_matches_oracle_fed_the_same_columns(dev, prec, mode, opkind):
+    """Nystrom(sketch='colsample') never forms Omega or an n x n x r product (Y = K[:, J] directly, Core = rows J of
+    Y); rho, S, P x and P^-1 x equal the oracle's Nystrom (the restated reference algorithm) fed the dense
+    Omega = sqrt(n / r) [e_j]."""
+    dt = DTYPES[prec]
+    g = torch.Generator().manual_seed(9)
+    n, d, r = 400, 4, 48
+    X = torch.randn(n, d, dtype=dt, generator=g) / d**0.5
+    K = ok.kernel_matrix("rbf", X, X, 1.0)
+    x = torch.randn(n, 3, dtype=dt, generator=g)
+    reg = 1e-2
+    torch.manual_seed(77)
+    Om = sketches.get_sketch("colsample", "right", r, n, dtype=dt, device=dev).Omega_mat.cpu()
+    st = on.build(K, Om, reg)
+    on.update_damping(st, reg, adaptive=(mode == "adaptive"))
+    Xd = X.to(dev)
+    A = RBFLinOp(Xd, Xd, KernelConfig(lengthscale=1.0)) if opkind == "kernel" else K.to(dev)
+    P = Nystrom(NystromConfig(rank=r, rho=reg, sketch="colsample", damping_mode=mode))
+    torch.manual_seed(77)  # the same draw
+    P._update(A, dev)
+    P._update_damping(reg)
+    tol = TOL[dt] if dt == torch.float64 else dict(rtol=2e-3, atol=2e-3)
+    assert abs(P.config.rho - st.rho) <= tol["atol"] + tol["rtol"] * abs(st.rho)
+    torch.testing.assert_close(P.S.cpu(), st.S, **tol)
+    torch.testing.assert_close((P @ x.to(dev)).cpu(), on.matmul(st, x), **tol)
+    ref = on.inverse_matmul(st, x)
+    got = (P._inv @ x.to(dev)).cpu()
+    assert (got - ref).abs().max() <= 10 * tol["rtol"] * ref.abs().max() + tol["atol"]
+
+
+def test_linsys_pcg_with_colsample_nystrom_converges_like_the_oracle(dev):
+    """End to end: LinSys.solve(PCG, Nystrom(colsample)) on an RBF system - the oracle's PCG with the oracle's
+    Nystrom fed the same columns takes the same number of iterations to the same residual."""
+    from oracle import linsys as ol
+    from oracle import pcg as opcg
+
+    dt = torch.float64
+    g = torch.Generator().manual_seed(3)
+    n, d, r = 600, 5, 64
+    X = torch.randn(n, d, dtype=dt, generator=g) / d**0.5
+    B = torch.randn(n, 2, dtype=dt, generator=g)
+    K = ok.kernel_matrix("rbf", X, X, 1.0)
+    reg = 1e-4 * n
+    torch.manual_seed(31)
+    Om = sketches.get_sketch("colsample", "right", r, n, dtype=dt, device=dev).Omega_mat.cpu()
+    st = on.build(K, Om, reg)
+    on.update_damping(st, reg, adaptive=True)
+    ref = opcg.BlockPCG(lambda V: K @ V, lambda R: on.inverse_matmul(st, R), B, reg, torch.zeros_like(B))
+    Wref, logref = ol.run(ref, lambda V: K @ V, B, reg, 300, 0.0, 1e-8, callback_freq=5)
+    Xd = X.to(dev)
+    A = RBFLinOp(Xd, Xd, KernelConfig(lengthscale=1.0))
+    cfg = PCGConfig(device=dev, max_iters=300, atol=0.0, rtol=1e-8,
+                    precond_config=NystromConfig(rank=r, rho=reg, sketch="colsample"))
+    torch.manual_seed(31)
+    W, log = LinSys(A, B.to(dev), reg=reg).solve(cfg, torch.zeros(n, 2, dtype=dt, device=dev), callback_freq=5)
+    assert abs(max(log) - max(logref)) <= 5
+    for i in sorted(log)[:3]:
+        torch.testing.assert_close(log[i]["metrics"]["internal_metrics"]["rel_res"].cpu(), logref[i]["rel_res"],
+                                   rtol=1e-6, atol=0)
+    assert float((W.cpu() - Wref).norm() / Wref.norm()) < 1e-5
+
+
+def test_skpre_with_colsample_sketch(dev, prec):
+    """SkPre(sketch='colsample'): Y = Omega A is a row gather; L equals the factor built from the dense Omega."""
+    dt = DTYPES[prec]
+    g = torch.Generator().manual_seed(4)
+    m, d, s = 500, 12, 96
+    A = torch.randn(m, d, dtype=dt, generator=g)
+    torch.manual_seed(41)
+    Om = sketches.get_sketch("colsample", "left", s, m, dtype=dt, device=dev).Omega_mat.cpu()
+    Y = Om @ A
+    Lref = torch.linalg.cholesky((Y.T @ Y).double() + 1e-3 * torch.eye(d, dtype=torch.float64))
+    P = SkPre(SkPreConfig(sketch_size=s, rho=1e-3, sketch="colsample"))
+    torch.manual_seed(41)
+    P._update(A.to(dev), dev)
+    tol = TOL[dt] if dt == torch.float64 else dict(rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(P.L.cpu().double(), Lref, **tol)
