@@ -21,37 +21,9 @@
 
 #include "rk_common.h"
 #include "rk_kerneltile.h"
+#include "rk_symm.h"
 
 namespace rk {
-
-struct SymLayout {
-    int64_t n;
-    int W;
-    int64_t first, stride;
-
-    __host__ __device__ int64_t strips_total() const { return (n + W - 1) / W; }
-    __host__ __device__ int64_t strips_local() const {
-        const int64_t S = strips_total();
-        return first < S ? (S - first + stride - 1) / stride : 0;
-    }
-    __host__ __device__ int64_t strip(int64_t t) const { return first + t * stride; }
-    __host__ __device__ int64_t rows(int64_t t) const {
-        const int64_t r = (strip(t) + 1) * W;
-        return r < n ? r : n;
-    }
-    // stored rows before local strip t (only the globally last strip is clipped, and it can
-    // only be the last local one, so every earlier strip s' has (s'+1) W rows)
-    __host__ __device__ int64_t row_offset(int64_t t) const {
-        return (int64_t)W * (t * (first + 1) + stride * (t * (t - 1) / 2));
-    }
-    __host__ __device__ int64_t total_rows() const {
-        const int64_t T = strips_local();
-        return T ? row_offset(T - 1) + rows(T - 1) : 0;
-    }
-};
-
-template <typename T>
-constexpr int strip_width() { return kWave * Vec16<T>::N; }
 
 // tuning knobs (overridable at build time for experiments: tools/variants.sh + tools/ab.py)
 #ifndef RK_SYMM_ITEM_ROWS
@@ -310,7 +282,6 @@ symm_strip_kernel(const TS* __restrict__ Kp, SymLayout L, const T* __restrict__ 
 // The 16-byte chunks of a staged row are XOR-swizzled with the row index: both read patterns (16
 // rows x one chunk, one row x 16 chunks) are bank-conflict free.  V is first copied into a zero-
 // padded [round_up(n, 256)][16] array so that every operand load is an aligned, unconditional one.
-constexpr int SMK = 16;                        // right-hand sides carried (k is padded up to it)
 template <typename T, int TR>
 constexpr size_t sm_smem_bytes() {  // staged tiles (TR KiB each) + V rows of the tile + row parts of the column slices
     return (size_t)(2 * TR * 1024) + (size_t)(2 * TR * SMK + 2 * (4 / (TR / 16)) * TR * SMK) * sizeof(T);
@@ -600,43 +571,6 @@ symm_finish_kernel(SymLayout L, int K, int KT, const T* __restrict__ Prow, const
 // are folded into a second set every 8 tiles (the matrix cores' float32 accumulation truncates, ~1e-8 per
 // step of a chain).  Tables, work items and the finishing kernel are those of the kernels above; the
 // per-column unscaling rides in the finishing kernel.
-constexpr int H2_TR = 32;                 // rows per tile
-constexpr int H2_ROWB = 544;              // bytes of one image row (256 halves + 32 bytes of padding)
-// byte offset of 16-column block c16 (0 .. 15) of image row `row`: the blocks of rows with bit 2 != bit 3 are
-// XOR-ed with 4 (found by exhaustive search over strides and XOR masks: with it the operand fetch of the row part
-// (ds_read_b128, 16 rows x 4 chunks per lane group), the transposed fetch of the column part (ds_read_b64_tr_b16, rows
-// q and 8 + q in one 32-lane half) and the 8-byte stores are ALL bank-conflict free)
-__host__ __device__ __forceinline__ int h2_off(int row, int c16) {
-    return row * H2_ROWB + ((c16 ^ (4 * (((row >> 3) ^ (row >> 2)) & 1))) << 5);
-}
-constexpr int H2_PIECE = H2_TR * H2_ROWB;  // one piece of one tile: 16 896 bytes
-constexpr int H2_FOLD = 8;                // tiles between folds of the column accumulators
-typedef unsigned int h2_u4 __attribute__((ext_vector_type(4)));
-typedef unsigned int h2_u2 __attribute__((ext_vector_type(2)));
-typedef float h2_acc __attribute__((ext_vector_type(4)));
-typedef _Float16 h2_h8 __attribute__((ext_vector_type(8)));
-typedef short h2_s4 __attribute__((ext_vector_type(4)));
-constexpr size_t h2_smem_bytes() {  // 2 buffers x 2 pieces + row parts of the 2 column halves (2 buffers)
-    return (size_t)(2 * 2 * H2_PIECE) + (size_t)(2 * 2 * H2_TR * SMK) * sizeof(float);
-}
-
-__device__ __forceinline__ void h2_split2(float a, float b, unsigned& h, unsigned& m) {
-    const _Float16 ha = (_Float16)a, hb = (_Float16)b;   // round to nearest even
-    const float ra = a - (float)ha, rb = b - (float)hb;  // exact
-    const _Float16 ma = (_Float16)ra, mb = (_Float16)rb;
-    h = (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
-    m = (unsigned)__builtin_bit_cast(unsigned short, ma) | ((unsigned)__builtin_bit_cast(unsigned short, mb) << 16);
-}
-__device__ __forceinline__ h2_acc h2_mfma(h2_u4 a, h2_u4 b, h2_acc c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h2_h8, a), __builtin_bit_cast(h2_h8, b), c, 0, 0, 0);
-}
-// h.h + h.m + m.h, small terms first
-__device__ __forceinline__ h2_acc h2_mfma3(const h2_u4 (&a)[2], const h2_u4 (&b)[2], h2_acc c) {
-    c = h2_mfma(a[1], b[0], c);
-    c = h2_mfma(a[0], b[1], c);
-    return h2_mfma(a[0], b[0], c);
-}
-
 // largest |V[:, c]| per column (float bits; non-negative floats order like integers)
 __global__ void __launch_bounds__(256)
 h2_absmax_kernel(const float* __restrict__ V, int64_t n, int k, int64_t ldv, unsigned* __restrict__ out) {
@@ -805,12 +739,19 @@ symm_strip_h2_kernel(const float* __restrict__ Kp, SymLayout L, const unsigned s
             for (int e = tid; e < TR * SMK; e += SYMM_THREADS) {
                 const int r = e >> 4, c = e & 15;
                 const float sum = rp[e] + rp[TR * SMK + e];
+#if defined(RK_H2_PROBE_NOTABLE)
+                if (r < live && c < ktab && sum == 123.456f) __builtin_nontemporal_store(sum, &pr[r * ktab + c]);
+#else
                 if (r < live && c < ktab) __builtin_nontemporal_store(sum, &pr[r * ktab + c]);
+#endif
             }
         };
         auto compute = [&](int buf, int tl) {
             if (tl > 0) flush_rows(buf ^ 1, tl - 1);  // (RP[buf ^ 1] was completed before the last barrier)
             const unsigned char* tb = TB + buf * 2 * H2_PIECE;
+#if defined(RK_H2_PROBE_NOMFMA)
+            if (sa != 0.f) return;
+#endif
             // ---- row part: A = rows 16 rb + lr, columns 128 cs + 32 s + 8 lq .. + 8 -----------------------
             h2_acc crow;
 #pragma unroll
@@ -886,16 +827,6 @@ symm_strip_h2_kernel(const float* __restrict__ Kp, SymLayout L, const unsigned s
         }
         __syncthreads();  // RP / TB are reused by the next item
     }
-}
-
-template <typename T>
-static SymLayout make_layout(int64_t n, int64_t first, int64_t stride) {
-    SymLayout L;
-    L.n = n;
-    L.W = strip_width<T>();
-    L.first = first;
-    L.stride = stride;
-    return L;
 }
 
 template <typename T, typename TS>
@@ -1078,6 +1009,20 @@ static size_t symm_h2_ws_bytes(int64_t n, int64_t first, int64_t stride) {
     return 256 + vt + prow + pcol;
 }
 
+int h2_prepare_v(const float* V, int64_t n, int64_t npad, int64_t k, int64_t ldv, double kmax, unsigned* info,
+                 unsigned short* Vt, int* ea_out, hipStream_t st) {
+    int ex;
+    frexp(kmax, &ex);
+    const int ea = 14 - ex;  // stored entries <= kmax < 2^ex: scaled below 2^14
+    *ea_out = ea;
+    if (hipMemsetAsync(info, 0, 256, st) != hipSuccess) return launch_status("rk_symm_matmat_f16x2(memset)");
+    hipLaunchKernelGGL(h2_absmax_kernel, dim3(256), dim3(256), 0, st, V, n, (int)k, ldv, info);
+    hipLaunchKernelGGL(h2_scale_kernel, dim3(1), dim3(64), 0, st, info, ea);
+    hipLaunchKernelGGL(h2_split_v_kernel, dim3((unsigned)ceil_div((npad / 8) * SMK, 256)), dim3(256), 0, st, V, n, npad,
+                       (int)k, ldv, info, Vt);
+    return launch_status("rk_symm_matmat_f16x2(split)");
+}
+
 static int symm_matmat_h2_impl(const float* Kp, int64_t n, int64_t first, int64_t stride, double kmax, const float* V,
                                int64_t k, int64_t ldv, double alpha, double shift, float* Y, int64_t ldy, void* ws,
                                size_t ws_bytes, hipStream_t st) {
@@ -1094,15 +1039,8 @@ static int symm_matmat_h2_impl(const float* Kp, int64_t n, int64_t first, int64_
     unsigned short* Vt = reinterpret_cast<unsigned short*>(static_cast<char*>(ws) + 256);
     float* Prow = reinterpret_cast<float*>(Vt + 2 * SMK * npad);
     float* Pcol = Prow + (size_t)round_up(L.total_rows() * k, 4);
-    int ex;
-    frexp(kmax, &ex);
-    const int ea = 14 - ex;  // stored entries <= kmax < 2^ex: scaled below 2^14
-    if (hipMemsetAsync(info, 0, 256, st) != hipSuccess) return launch_status("rk_symm_matmat_f16x2(memset)");
-    hipLaunchKernelGGL(h2_absmax_kernel, dim3(256), dim3(256), 0, st, V, n, (int)k, ldv, info);
-    hipLaunchKernelGGL(h2_scale_kernel, dim3(1), dim3(64), 0, st, info, ea);
-    hipLaunchKernelGGL(h2_split_v_kernel, dim3((unsigned)ceil_div((npad / 8) * SMK, 256)), dim3(256), 0, st, V, n, npad,
-                       (int)k, ldv, info, Vt);
-    int rc = launch_status("rk_symm_matmat_f16x2(split)");
+    int ea = 0;
+    int rc = h2_prepare_v(V, n, npad, k, ldv, kmax, info, Vt, &ea, st);
     if (rc != RK_OK) return rc;
     if (T_loc > 0) {
         int64_t total_items = 0;
@@ -1244,7 +1182,9 @@ extern "C" int rk_symm_matmat(int dtype, int store_dtype, const void* Kp, int64_
 
 extern "C" size_t rk_symm_matmat_f16x2_ws_bytes(int64_t n, int64_t k, int64_t strip_first, int64_t strip_stride) {
     if (n <= 0 || k < 1 || k > SMK || strip_stride < 1 || strip_first < 0 || strip_first >= strip_stride) return 0;
-    return symm_h2_ws_bytes(n, strip_first, strip_stride);
+    const size_t a = symm_h2_ws_bytes(n, strip_first, strip_stride);
+    const size_t b = symm_h2blk_ws_bytes(n, k, strip_first, strip_stride);
+    return a > b ? a : b;  // (either implementation can run in it)
 }
 
 extern "C" int rk_symm_matmat_f16x2(const void* Kp, int64_t n, int64_t strip_first, int64_t strip_stride, double kmax,
@@ -1258,6 +1198,12 @@ extern "C" int rk_symm_matmat_f16x2(const void* Kp, int64_t n, int64_t strip_fir
     RK_REQUIRE(ldv >= k && ldy >= k, "rk_symm_matmat_f16x2: leading dimension too small");
     RK_REQUIRE(kmax > 0.0 && kmax < 1e30, "rk_symm_matmat_f16x2: kmax must bound the stored entries (got %g)", kmax);
     RK_REQUIRE(aligned16(Kp) && aligned16(ws), "rk_symm_matmat_f16x2: packed matrix and workspace must be 16-byte aligned");
-    return symm_matmat_h2_impl((const float*)Kp, n, strip_first, strip_stride, kmax, (const float*)V, k, ldv, alpha,
-                               diag_shift, (float*)Y, ldy, ws, ws_bytes, static_cast<hipStream_t>(stream));
+    // default: the block form (rk_symmblk.hip: four strips side by side per work item, a quarter of the partial
+    // tables); RK_SYMM_H2_IMPL=strip keeps the round-3 strip kernel (A/B partner)
+    const char* impl = getenv("RK_SYMM_H2_IMPL");
+    if (impl != nullptr && impl[0] == 's')
+        return symm_matmat_h2_impl((const float*)Kp, n, strip_first, strip_stride, kmax, (const float*)V, k, ldv, alpha,
+                                   diag_shift, (float*)Y, ldy, ws, ws_bytes, static_cast<hipStream_t>(stream));
+    return symm_matmat_h2blk_impl((const float*)Kp, n, strip_first, strip_stride, kmax, (const float*)V, k, ldv, alpha,
+                                  diag_shift, (float*)Y, ldy, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }

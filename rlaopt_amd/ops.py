@@ -305,8 +305,9 @@ class HipBackend:
         """alpha * (this rank's partial of) K V + diag_shift * V from the packed triangle; the
         arithmetic type is V's dtype, the storage type Kp's (float32 storage under float64 V).
         ``kmax``: a bound on the magnitude of the stored entries (the operator's const_scaling) - with it,
-        float32 products of RK_SYMM_F16X2_MIN (4) .. 16 columns run on the 16-bit matrix cores
-        (``rk_symm_matmat_f16x2``)."""
+        float32 products of RK_SYMM_F16X2_MIN (1) .. 16 columns run on the 16-bit matrix cores
+        (``rk_symm_matmat_f16x2``; since round 4 its block form is faster than the float32 register kernel at
+        every width: n = 200 000, k = 1: 12.03 against 12.35 ms on the same card)."""
         dev = _req(Kp, V)
         V2, squeeze = _as2d(V)
         if V2.shape[0] != n:
@@ -318,7 +319,7 @@ class HipBackend:
         out = torch.empty((n, k), dtype=V2.dtype, device=dev)
         es = V2.element_size()
         if (kmax is not None and kmax > 0 and V2.dtype == torch.float32 and Kp.dtype == torch.float32
-                and k >= int(os.environ.get("RK_SYMM_F16X2_MIN", "4")) and os.environ.get("RK_SYMM_F16X2", "1") != "0"):
+                and k >= int(os.environ.get("RK_SYMM_F16X2_MIN", "1")) and os.environ.get("RK_SYMM_F16X2", "1") != "0"):
             for c0 in range(0, k, 16):
                 kc = min(16, k - c0)
                 ws, wsn = self._workspace(dev, self._lib.rk_symm_matmat_f16x2_ws_bytes(n, kc, first, stride))

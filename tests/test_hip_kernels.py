@@ -897,7 +897,8 @@ def test_integration_md_stub_runs_against_the_oracle(be, prec, name, kind):
 
 @pytest.mark.parametrize("n,k,first,stride", [(300, 5, 0, 1), (1000, 16, 0, 1), (2304, 7, 0, 1), (3000, 10, 0, 1),
                                              (5000, 16, 0, 1), (4100, 9, 1, 3), (2600, 12, 0, 2), (1500, 1, 0, 1),
-                                             (33, 6, 0, 1)])
+                                             (33, 6, 0, 1), (1025, 4, 0, 1), (2049, 3, 0, 1), (6200, 11, 0, 1),
+                                             (9000, 16, 2, 5), (7000, 8, 0, 8)])
 def test_symm_matmat_f16x2_matrix_core_strip_product(be, n, k, first, stride):
     """rk_symm_matmat_f16x2: the packed symmetric product for up to 16 right-hand sides on the 16-bit matrix
     cores (two float16 pieces per factor, row reads and transposing reads of one LDS image) against the float64
@@ -917,15 +918,20 @@ def test_symm_matmat_f16x2_matrix_core_strip_product(be, n, k, first, stride):
     for f in range(stride):
         Kp = be.sympack_materialize("matern32", Xd, 0.9, scale=scale, first=f, stride=stride)
         import os as _os
-        _os.environ["RK_SYMM_F16X2_MIN"] = "1"
+        got = be.symm_matmat(Kp, n, Vd, alpha=-1.5, diag_shift=0.25 if f == 0 else 0.0, first=f, stride=stride,
+                             kmax=scale)
+        again = be.symm_matmat(Kp, n, Vd, alpha=-1.5, diag_shift=0.25 if f == 0 else 0.0, first=f, stride=stride,
+                               kmax=scale)
+        assert torch.equal(got, again)  # fixed-order tables: reproducible bit for bit
+        # the round-3 strip form of the same product (RK_SYMM_H2_IMPL=strip) stays available as A/B partner
+        _os.environ["RK_SYMM_H2_IMPL"] = "strip"
         try:
-            got = be.symm_matmat(Kp, n, Vd, alpha=-1.5, diag_shift=0.25 if f == 0 else 0.0, first=f, stride=stride,
-                                 kmax=scale)
-            again = be.symm_matmat(Kp, n, Vd, alpha=-1.5, diag_shift=0.25 if f == 0 else 0.0, first=f, stride=stride,
+            strip = be.symm_matmat(Kp, n, Vd, alpha=-1.5, diag_shift=0.25 if f == 0 else 0.0, first=f, stride=stride,
                                    kmax=scale)
         finally:
-            del _os.environ["RK_SYMM_F16X2_MIN"]
-        assert torch.equal(got, again)  # fixed-order tables: reproducible bit for bit
+            del _os.environ["RK_SYMM_H2_IMPL"]
+        if stride == 1:
+            assert float(((got - strip).double().norm(dim=0) / strip.double().norm(dim=0)).max()) < 3e-6
         parts.append(got.cpu().double())
         if stride == 1:  # the float32 kernels it replaces (register kernel / float32 matrix cores)
             old = be.symm_matmat(Kp, n, Vd, alpha=-1.5, diag_shift=0.25)

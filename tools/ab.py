@@ -23,6 +23,7 @@ from rlaopt_amd.ops import get_backend  # noqa: E402
 
 
 def load_variant(name):
+    name = name.split("@")[0]  # "main@strip": the main build with RK_SYMM_H2_IMPL=strip around its calls
     path = os.path.join(ROOT, "build_var", name, "librk_hip.so") if name != "main" else _lib.LIB_PATH
     lib = ctypes.CDLL(path)
     for sym, (restype, argtypes) in _lib.SIGNATURES.items():
@@ -46,7 +47,7 @@ def time_call(fn, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("variants", nargs="+")
-    ap.add_argument("--kernel", default="symm", choices=["symm", "skinny", "kmatmat"])
+    ap.add_argument("--kernel", default="symm", choices=["symm", "symmh2", "skinny", "kmatmat"])
     ap.add_argument("--n", type=int, default=200000)
     ap.add_argument("--rows", type=int, default=50000)
     ap.add_argument("--k", type=int, default=1)
@@ -83,6 +84,21 @@ def main():
                                         Y.data_ptr(), k, ws.data_ptr(), wsn, stream)
                 assert rc == 0, lib.rk_last_error()
             return fn
+    elif a.kernel == "symmh2":  # the float16-split packed symmetric product (rk_symm_matmat_f16x2)
+        X = torch.randn(n, 64, dtype=dt, device=dev) / 8
+        Kp = be.sympack_materialize("rbf", X, 1.0, first=0, stride=a.stride)
+        Y = torch.empty(n, k, dtype=dt, device=dev)
+        nbytes = Kp.numel() * Kp.element_size()
+
+        def call(lib):
+            wsn = lib.rk_symm_matmat_f16x2_ws_bytes(n, k, 0, a.stride)
+            ws = torch.empty(wsn, dtype=torch.uint8, device=dev)
+
+            def fn():
+                rc = lib.rk_symm_matmat_f16x2(Kp.data_ptr(), n, 0, a.stride, 1.0, V.data_ptr(), k, k, 1.0, 0.1,
+                                              Y.data_ptr(), k, ws.data_ptr(), wsn, stream)
+                assert rc == 0, lib.rk_last_error()
+            return fn
     elif a.kernel == "kmatmat":
         X = torch.randn(n, a.d, dtype=dt, device=dev) / a.d**0.5
         blk = torch.randperm(n, device=dev)[: a.blk].contiguous()
@@ -116,7 +132,20 @@ def main():
                                           None, 0, 0.0, 0, Y.data_ptr(), k, ws.data_ptr(), wsn, stream)
                 assert rc == 0, lib.rk_last_error()
             return fn
-    fns = {v: call(lib) for v, lib in libs.items()}
+    def with_env(v, fn):
+        if "@" not in v:
+            def plain():
+                os.environ.pop("RK_SYMM_H2_IMPL", None)
+                fn()
+            return plain
+        impl = v.split("@")[1]
+
+        def wrapped():
+            os.environ["RK_SYMM_H2_IMPL"] = impl
+            fn()
+        return wrapped
+
+    fns = {v: with_env(v, call(lib)) for v, lib in libs.items()}
     ref = None
     for v, fn in fns.items():  # same answers (fp reassociation only)
         fn()
