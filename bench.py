@@ -567,8 +567,13 @@ def main():
                 "parallelism": f"row-shard x{world}",
             },
             "roofline": {
-                "kernel": ("rk_symm_matmat (symm_strip_kernel): strip-packed upper triangle, every "
-                           "stored entry used for y[i] and y[j]; algorithmic bytes = packed triangle + V + Y"
+                "kernel": (("rk_symm_matmat_f16x2 (symm_blk_h2_kernel + finish): strip-packed upper triangle, every stored "
+                            "entry used for y[i] and y[j], four strips side by side per work item, both uses on the 16-bit "
+                            "matrix cores with two float16 pieces per factor (float32 accuracy); "
+                            if (args.dtype == "f32" and A._sym is not None and A._sym.store_dtype == torch.float32
+                                and A._sym.Kp.numel() * 4 >= 24e9) else
+                            "rk_symm_matmat (symm_strip_kernel + finish): strip-packed upper triangle, every stored entry "
+                            "used for y[i] and y[j]; ") + "algorithmic bytes = packed triangle + V + Y"
                            if mode.startswith("sympack") else
                            "rk_matmat_skinny (skinny_nn_kernel<float,1,8>): row-major shard; algorithmic "
                            "bytes = (n_loc n + n k + n_loc k) * 4"),

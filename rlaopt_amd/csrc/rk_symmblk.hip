@@ -10,13 +10,14 @@
 //      instructions" with two tiles in flight, so the time from a tile's arrival to the re-issue of its registers'
 //      next loads (Little's law: rate = bytes in flight / (latency + that time)) includes the arithmetic.
 //
-// Here a work item is a BLOCK of G = 4 strips side by side x H = 1024 rows (4 MiB), walked row-tile by row-tile:
+// Here a work item is a BLOCK of G = 4 strips side by side x H rows (H = 2048: 8 MiB; chosen per call, 2048 .. 256:
+// make_blk_layout), walked row-tile by row-tile:
 // the four 32 x 256 tiles of a row-tile are consumed back to back, so
 //   * a row's partial sum is carried across the four strips in the accumulators and written ONCE per row-tile: the
 //     (group, row) table has k floats per 4 KiB read - a quarter of the strip kernel's;
 //   * the column sums of all four strips stay in registers for the whole item (8 accumulators of 4 registers per wave;
-//     folded into a second set every 8 row-tiles like the strip kernel's): k floats per column and 1024 rows as before.
-//   Tables per element read: k (1/1024 + 1/1024) instead of k (1/256 + 1/1024): 2.5 x fewer bytes written here and
+//     folded into a second set every 8 row-tiles like the strip kernel's): k floats per column and H rows.
+//   Tables per element read: k (1/1024 + 1/2048) instead of k (1/256 + 1/1024): 3.3 x fewer bytes written here and
 //   read by the finishing kernel.
 // One workgroup of 8 waves per CU owns the CU's LDS: two float16 images of a tile (hi / lo pieces, the conflict-free
 // layout of the strip kernel, double-buffered: one barrier per tile), the split V of the group's 4 x 256 columns in
@@ -41,7 +42,7 @@ namespace rk {
 #define RK_B2_G 4
 #endif
 #ifndef RK_B2_H
-#define RK_B2_H 1024
+#define RK_B2_H 0  // rows per item: 0 = chosen per call (2048 .. 256, see make_blk_layout), else fixed (a multiple of 32)
 #endif
 #ifndef RK_B2_S
 #define RK_B2_S 4
@@ -50,26 +51,28 @@ namespace rk {
 #define RK_B2_FOLD 8  // row-tiles between folds of the column accumulators (0: never)
 #endif
 constexpr int B2_G = RK_B2_G;        // strips per group
-constexpr int B2_H = RK_B2_H;        // rows per item
+constexpr int B2_H_FIXED = RK_B2_H;
 constexpr int B2_S = RK_B2_S;        // tiles in flight per workgroup
 constexpr int B2_FOLD = RK_B2_FOLD;
 constexpr int B2_THREADS = 512;
 constexpr int B2_W = 256;
 constexpr int B2_TR = H2_TR;         // rows per tile (32)
 static_assert(B2_S % B2_G == 0 && B2_S % 2 == 0, "the unrolled tile loop keeps the strip index and the buffer parity static");
-static_assert(B2_H % B2_TR == 0 && B2_G == 4, "items are whole row-tiles; the LDS plan assumes 4 strips");
+static_assert(B2_H_FIXED % B2_TR == 0 && B2_G == 4, "items are whole row-tiles; the LDS plan assumes 4 strips");
 
 // LDS plan (bytes)
 constexpr int B2_TB = 0;                                   // [2 buffers][2 pieces][32 rows][544 B]
 constexpr int B2_VS = B2_TB + 2 * 2 * H2_PIECE;            // [G][2 pieces][4 column slices][2 steps][64 lanes][16 B]
 constexpr int B2_RP = B2_VS + B2_G * 2 * 4 * 2 * 1024;     // [2][4 slices][32 rows][16 rhs] float
 constexpr int B2_VI = B2_RP + 2 * 4 * B2_TR * SMK * 4;     // [2][2 pieces][64 lanes][16 B]
-constexpr int B2_SMEM = B2_VI + 2 * 2 * 1024;
+constexpr int B2_NEXT = B2_VI + 2 * 2 * 1024;              // next work item (dynamic scheduling)
+constexpr int B2_SMEM = B2_NEXT + 16;
 static_assert(B2_SMEM <= 160 * 1024, "one workgroup per CU owns the LDS");
 
 struct BlkLayout {
     SymLayout L;
     int64_t T_loc, Q, max_chunks;
+    int H;  // rows per item
     // rows of group q = rows of its last strip (strip heights grow with the strip index)
     __host__ __device__ int64_t grp_rows(int64_t q) const {
         int64_t t = q * B2_G + B2_G - 1;
@@ -83,18 +86,36 @@ struct BlkLayout {
     __host__ __device__ int64_t prow_rows() const { return Q ? prow_off(Q - 1) + grp_rows(Q - 1) : 0; }
 };
 
-static BlkLayout make_blk_layout(int64_t n, int64_t first, int64_t stride) {
+static int64_t blk_items(const BlkLayout& B) {
+    int64_t total = 0;
+    for (int64_t q = 0; q < B.Q; ++q) total += ceil_div(B.grp_rows(q), B.H);
+    return total;
+}
+
+// Rows per item.  Taller items shrink the (item, column) table (k floats per column and item), but the persistent grid
+// needs enough items per workgroup for an even finish (items are claimed dynamically: the tail is at most one item long):
+// the tallest of 2048 / 1024 / 512 / 256 that still gives every CU ~24 items (n = 200 000 on one GPU: 2048; its 1/8
+// shard of an 8-rank run: 512).
+static BlkLayout make_blk_layout(int64_t n, int64_t first, int64_t stride, int64_t cus = 256) {
     BlkLayout B;
     B.L = make_layout<float>(n, first, stride);
     B.T_loc = B.L.strips_local();
     B.Q = ceil_div(B.T_loc, B2_G);
-    B.max_chunks = ceil_div(n, B2_H);
+    B.H = B2_H_FIXED;
+    if (B2_H_FIXED == 0) {
+        for (int h : {2048, 1024, 512, 256}) {
+            B.H = h;
+            if (blk_items(B) >= 24 * cus) break;
+        }
+    }
+    B.max_chunks = ceil_div(n, B.H);
     return B;
 }
 
 __global__ void __launch_bounds__(B2_THREADS, 2)
 symm_blk_h2_kernel(const float* __restrict__ Kp, BlkLayout B, const unsigned short* __restrict__ Vt, int64_t npad,
-                   float sa, int ktab, float* __restrict__ Prow, float* __restrict__ Pcol, int64_t total_items) {
+                   float sa, int ktab, float* __restrict__ Prow, float* __restrict__ Pcol, int64_t total_items,
+                   unsigned* __restrict__ counter) {
     constexpr int G = B2_G, S = B2_S, TR = B2_TR, W = B2_W;
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
     const SymLayout& L = B.L;
@@ -114,18 +135,28 @@ symm_blk_h2_kernel(const float* __restrict__ Kp, BlkLayout B, const unsigned sho
     const unsigned short* vsrc = Vt + (int64_t)(tid >> 4) * npad + 2 * (tid & 15);
     const int vi_st = (tid >> 8) * 1024 + ((((tid & 15) >> 2) * 16 + ((tid >> 4) & 15)) * 16) + ((tid & 15) & 3) * 4;
 
+    // Work items are claimed from a device counter (zeroed by the caller) in ascending order - the resident grid sweeps
+    // ONE contiguous window of the packed triangle (a contiguous range of row-tiles per workgroup - equal work, one
+    // pipeline fill, column sums flushed once per group - was built and measured: 13.3 against 12.1 ms at k = 1, the 256
+    // far-apart streams advance in lockstep and collide in the memory system).  The first item is blockIdx.x, every later
+    // one gridDim.x + (ticket); the ticket for the NEXT item is drawn when an item starts, so its latency is hidden.  Ids
+    // only grow per workgroup, so (q, before) walk forward; results do not depend on who computes what (tables are
+    // indexed by item).
     int64_t q = 0, before = 0;
-    for (int64_t id = blockIdx.x; id < total_items; id += gridDim.x) {
+    int64_t id = blockIdx.x;
+    while (id < total_items) {
+        unsigned ticket = 0;
+        if (tid == 0) ticket = atomicAdd(counter, 1u);
         for (;;) {
-            const int64_t cnt = (B.grp_rows(q) + B2_H - 1) / B2_H;
+            const int64_t cnt = (B.grp_rows(q) + B.H - 1) / B.H;
             if (id < before + cnt) break;
             before += cnt;
             ++q;
         }
         const int64_t chunk = id - before;
         const int64_t grows = uniform64(B.grp_rows(q));
-        const int64_t r_lo = uniform64(chunk * B2_H);
-        const int64_t r_hi = r_lo + B2_H < grows ? r_lo + B2_H : grows;
+        const int64_t r_lo = uniform64(chunk * (int64_t)B.H);
+        const int64_t r_hi = r_lo + B.H < grows ? r_lo + B.H : grows;
         const int ntr = (int)((r_hi - r_lo + TR - 1) / TR);  // row-tiles of the item
         // the group's strips
         const float* base[G];
@@ -305,7 +336,9 @@ symm_blk_h2_kernel(const float* __restrict__ Kp, BlkLayout B, const unsigned sho
                     }
             }
         }
+        if (tid == 0) *reinterpret_cast<unsigned*>(sm_raw + B2_NEXT) = ticket;
         __syncthreads();  // LDS is reused by the next item
+        id = (int64_t)gridDim.x + __builtin_amdgcn_readfirstlane(*reinterpret_cast<const unsigned*>(sm_raw + B2_NEXT));
     }
 }
 
@@ -337,7 +370,7 @@ symm_blk_finish_kernel(BlkLayout B, int K, const float* __restrict__ Prow, const
             const int64_t tc = (blk - L.first) / L.stride;
             qc = tc / B2_G;
             gc = tc - qc * B2_G;
-            ncol = (blk * B2_W + B2_H - 1) / B2_H;  // items whose rows start above the strip's diagonal block
+            ncol = (blk * B2_W + B.H - 1) / B.H;  // items whose rows start above the strip's diagonal block
         }
         const int64_t jloc = i - blk * B2_W;
         auto term = [&](int64_t u) -> float {
@@ -365,8 +398,23 @@ symm_blk_finish_kernel(BlkLayout B, int K, const float* __restrict__ Prow, const
     }
 }
 
+static int64_t device_cus() {
+    static std::atomic<int> cu_count[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    int v = cu_count[dev & 63].load(std::memory_order_acquire);
+    if (v == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        (void)hipGetLastError();
+        v = cus > 0 ? cus : 256;
+        cu_count[dev & 63].store(v, std::memory_order_release);
+    }
+    return v;
+}
+
 size_t symm_h2blk_ws_bytes(int64_t n, int64_t k, int64_t first, int64_t stride) {
-    const BlkLayout B = make_blk_layout(n, first, stride);
+    const BlkLayout B = make_blk_layout(n, first, stride, device_cus());
     const size_t npad = (size_t)round_up(n, 256);
     const size_t vt = 2 * SMK * npad * sizeof(unsigned short);
     const size_t prow = (size_t)round_up(B.prow_rows() * k, 4) * sizeof(float);
@@ -377,7 +425,8 @@ size_t symm_h2blk_ws_bytes(int64_t n, int64_t k, int64_t first, int64_t stride) 
 int symm_matmat_h2blk_impl(const float* Kp, int64_t n, int64_t first, int64_t stride, double kmax, const float* V,
                            int64_t k, int64_t ldv, double alpha, double shift, float* Y, int64_t ldy, void* ws,
                            size_t ws_bytes, hipStream_t st) {
-    const BlkLayout B = make_blk_layout(n, first, stride);
+    const int64_t cus = device_cus();
+    const BlkLayout B = make_blk_layout(n, first, stride, cus);
     const size_t need = symm_h2blk_ws_bytes(n, k, first, stride);
     if (ws == nullptr || ws_bytes < need) {
         set_error("rk_symm_matmat_f16x2: workspace %zu B < required %zu B", ws_bytes, need);
@@ -392,10 +441,8 @@ int symm_matmat_h2blk_impl(const float* Kp, int64_t n, int64_t first, int64_t st
     int rc = h2_prepare_v(V, n, npad, k, ldv, kmax, info, Vt, &ea, st);
     if (rc != RK_OK) return rc;
     if (B.T_loc > 0) {
-        int64_t total_items = 0;
-        for (int64_t q = 0; q < B.Q; ++q) total_items += ceil_div(B.grp_rows(q), B2_H);
+        const int64_t total_items = blk_items(B);
         static std::atomic<unsigned long long> attr_devs{0};
-        static std::atomic<int> cu_count[64];
         int dev = 0;
         (void)hipGetDevice(&dev);
         const unsigned long long bit = 1ull << (dev & 63);
@@ -406,16 +453,12 @@ int symm_matmat_h2blk_impl(const float* Kp, int64_t n, int64_t first, int64_t st
                 set_error("rk_symm_matmat_f16x2: cannot reserve %d bytes of LDS", B2_SMEM);
                 return RK_ERR_LAUNCH;
             }
-            int cus = 0;
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
-            (void)hipGetLastError();
-            cu_count[dev & 63].store(cus > 0 ? cus : 256, std::memory_order_release);
             attr_devs.fetch_or(bit, std::memory_order_release);
         }
-        const int64_t resident = cu_count[dev & 63].load(std::memory_order_acquire);  // one workgroup per CU
+        const int64_t resident = cus;  // one workgroup per CU
         dim3 grid((unsigned)(total_items < resident ? total_items : resident));
         hipLaunchKernelGGL(symm_blk_h2_kernel, grid, dim3(B2_THREADS), B2_SMEM, st, Kp, B, Vt, npad,
-                           (float)ldexp(1.0, ea), (int)k, Prow, Pcol, total_items);
+                           (float)ldexp(1.0, ea), (int)k, Prow, Pcol, total_items, info + 60);  // (info is zeroed per call)
         rc = launch_status("rk_symm_matmat_f16x2(block)");
         if (rc != RK_OK) return rc;
     }

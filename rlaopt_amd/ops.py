@@ -318,7 +318,11 @@ class HipBackend:
         k = V2.shape[1]
         out = torch.empty((n, k), dtype=V2.dtype, device=dev)
         es = V2.element_size()
-        if (kmax is not None and kmax > 0 and V2.dtype == torch.float32 and Kp.dtype == torch.float32
+        # (one column over a small shard - the per-rank shape of an 8-GPU run, 10 GB - stays with the float32 register
+        # kernel: 1.55 against 1.69 ms; the block kernel's fixed costs amortise from ~25 GB on: 40 GB 5.90 against 6.15 ms,
+        # 80 GB 11.55 against 12.37 ms)
+        small_single = k == 1 and Kp.numel() * 4 < int(float(os.environ.get("RK_SYMM_F16X2_MIN_BYTES", "24e9")))
+        if (kmax is not None and kmax > 0 and V2.dtype == torch.float32 and Kp.dtype == torch.float32 and not small_single
                 and k >= int(os.environ.get("RK_SYMM_F16X2_MIN", "1")) and os.environ.get("RK_SYMM_F16X2", "1") != "0"):
             for c0 in range(0, k, 16):
                 kc = min(16, k - c0)

@@ -42,6 +42,7 @@ def main():
         for mode in modes:
             os.environ["RK_SYMM_WIDE"] = "0" if mode == "groups_of_4" else "1"
             os.environ["RK_SYMM_F16X2_MIN"] = "1"
+            os.environ["RK_SYMM_F16X2_MIN_BYTES"] = "0"
             kmax = 1.0 if mode == "f16x2" else None
             _sm = be.symm_matmat
             be_symm = lambda Kp_, n_, V_: _sm(Kp_, n_, V_, kmax=kmax)  # noqa: E731
@@ -64,6 +65,7 @@ def main():
             del want
         os.environ["RK_SYMM_WIDE"] = "1"
         os.environ.pop("RK_SYMM_F16X2_MIN", None)
+        os.environ.pop("RK_SYMM_F16X2_MIN_BYTES", None)
         print(json.dumps(rec), flush=True)
 
 
