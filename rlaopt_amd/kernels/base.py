@@ -82,6 +82,29 @@ def _same_points(A1: torch.Tensor, A2: torch.Tensor) -> bool:
 _UNSET = object()
 
 
+def _prefer_matrix_free(kind: str, X: torch.Tensor, expected_products: float) -> bool:
+    """Mode choice by modelled end-to-end time (RK_KERNEL_MODE=auto, symmetric float32 data on one device, nothing
+    materialised yet): strip-packed storage streams 2 n^2 bytes per product at ~6.9 TB/s but has to be allocated -
+    memory that an earlier process freed is cleared by the driver before it is handed out, ~15 ms per GB, paid by
+    roughly every third fresh process - and written (~1 ms per GB); the matrix-free product
+    recomputes the entries on the 16-bit matrix cores at ~3.1e12 pairs/s (11 % slower per product at d <= 64), needs no
+    storage, and its sketch product costs ~0.09 s more at n = 200 000.  With the expected allocation price
+    RK_ALLOC_MS_PER_GB (default 5 = 15 / 3; 0: never prefer matrix-free) the storage pays off from ~300 products on,
+    whatever n.  Memory the caching allocator already holds costs nothing."""
+    if X.dtype != torch.float32 or not X.is_cuda or X.shape[1] > 64 or kind not in ("rbf", "matern32", "matern52"):
+        return False
+    per_gb = float(os.environ.get("RK_ALLOC_MS_PER_GB", "5"))
+    if per_gb <= 0.0 or expected_products is None:
+        return False
+    n = X.shape[0]
+    gb = 2.0 * n * n / 1e9
+    cached_free = torch.cuda.memory_reserved(X.device) - torch.cuda.memory_allocated(X.device)
+    alloc_ms = 0.0 if cached_free >= gb * 1e9 else per_gb * gb
+    t_pack = alloc_ms + 1.0 * gb + expected_products * (gb / 6.9)           # ms
+    t_free = 0.09e3 * (n / 2e5) ** 2 + expected_products * (n * n / 3.1e9)  # ms (extra sketch time + products)
+    return t_free < t_pack
+
+
 def _gram_center(kind: str, A1: torch.Tensor, A2: torch.Tensor, lengthscale, device=None):
     """Centre for the matrix-core formulation of matrix-free products over (subsets of) the rows
     of A1 and A2, or None (``HipBackend.gram_center``; one host read-back, so operators cache the
@@ -252,9 +275,42 @@ class _KernelBlock:
             y = alpha * y + (beta * C if beta != 0.0 else 0.0)
         return y
 
+    def _matmat_wide_strips(self, x):
+        """K(X, X) @ x for MANY columns without n x n storage and without the float32 GEMM: the packed triangle is
+        written P cyclic strip subsets at a time into ONE temporary buffer (<= _FREE_PANEL_BYTES; subset f = strips
+        f, f + P, ... - the layout a rank of a P-rank run holds) and each subset's partial of K x comes from the
+        16-bit matrix cores (``rk_symm_gemm``); the partials add up.  Every entry is evaluated once (the row-major
+        panels evaluate the full square) and the product runs at the sketch kernel's rate instead of the float32
+        matrix cores': n = 200 000, r = 512: see DESIGN.md (0.77 s through panels)."""
+        be = get_backend()
+        n = self.A1.shape[0]
+        budget = _FREE_PANEL_BYTES
+        if x.is_cuda:
+            budget = min(budget, int(0.5 * torch.cuda.mem_get_info(x.device)[0]))
+        parts = max(1, -(-(n * n * 2 + n * 1024) // max(budget, 1)))  # packed float32 triangle = 2 n^2 bytes (+ diagonal blocks)
+        parts = min(parts, max(1, -(-n // 256)))
+        cap = max(be.sympack_elems(n, f, parts) for f in range(parts))
+        buf = torch.empty(cap, dtype=torch.float32, device=x.device)
+        xs = x if x.dtype == torch.float32 else x.float()
+        out = None
+        for f in range(parts):
+            Kp = be.sympack_materialize(self.kind, self.A1, self.config.lengthscale, scale=self.scale, first=f,
+                                        stride=parts, out=buf)
+            for c0 in range(0, xs.shape[1], 1024):
+                part = be.symm_gemm(Kp, n, xs[:, c0 : c0 + 1024], kmax=abs(self.scale), first=f, stride=parts,
+                                    tag="kernel_sketch_product")
+                if out is None:
+                    out = torch.zeros((n, xs.shape[1]), dtype=torch.float32, device=x.device)
+                out[:, c0 : c0 + 1024] += part
+        return out.to(x.dtype)
+
     def _matmat_wide(self, x):
         be = get_backend()
         m, n = self.A1.shape[0], self.A2.shape[0]
+        if (self._symmetric and m == n and self.A1.dtype == torch.float32 and x.is_cuda and x.ndim == 2
+                and self.scale != 0.0 and hasattr(be, "symm_gemm") and hasattr(be, "sympack_elems")
+                and os.environ.get("RK_FREE_WIDE_STRIPS", "1") != "0"):
+            return self._matmat_wide_strips(x)
         es = x.element_size()
         budget = _FREE_PANEL_BYTES
         if x.is_cuda:
@@ -333,6 +389,19 @@ class _KernelLinOp(TwoSidedLinOp, ScaleMixin):
         if self._sym is not None:
             return "sympack" if self._sym.store_dtype == self.dtype else "sympack(float32 storage)"
         return "materialize" if self._block.materialised else "matrix_free"
+
+    def _rk_plan(self, expected_products: float) -> None:
+        """Hint from a solver about how many products are coming (LinSys.solve: iterations + logged residuals +
+        the sketch): in auto mode, before anything has been materialised, the operator may decide to stay
+        storage-free (``_prefer_matrix_free``)."""
+        if (_mode_override() == "auto" and self._sym is not None and self._sym._Kp is None
+                and _gram_center(self._kind, self._A1, self._A2, self._kernel_config.lengthscale) is not None
+                and _prefer_matrix_free(self._kind, self._A1, expected_products)):
+            self._sym = None
+            self._block = _KernelBlock(self._kind, self._A1, self._A2, self._kernel_config)
+            self._block.materialised = False
+            self._matvec_fn = self._matmat_fn = self._block.matmat
+            self._rmatvec_fn = self._rmatmat_fn = self._block.rmatmat
 
     def _sym_matmat(self, x, diag_shift=0.0):
         cols = 1 if x.ndim == 1 else x.shape[1]

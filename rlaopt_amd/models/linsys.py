@@ -180,6 +180,13 @@ class LinSys(Model):
             ),
             sync=_device_sync(self._B),
         )
+        plan = getattr(self._A, "_rk_plan", None)
+        if plan is not None and _get_solver_name(solver_config) == "pcg":
+            # how many operator products this solve will ask for at most: one per iteration, one per logged residual
+            # (fused with an iteration's when narrow), the sketch counted as rank / 16 passes - a storage decision the
+            # operator may still take (kernels/base.py::_prefer_matrix_free)
+            rank = getattr(getattr(solver_config, "precond_config", None), "rank", 0) or 0
+            plan(solver_config.max_iters * (1.0 + 1.0 / max(callback_freq, 1)) + rank / 16.0)
         solver = _get_solver(model=self, W_init=W_init, solver_config=solver_config)
         self._active_solver = solver
         return self._train(

@@ -285,15 +285,26 @@ class HipBackend:
         return buf, bool(slot.get("ready")), slot
 
     # -- symmetric packed kernel matrices ------------------------------------------------------
-    def sympack_materialize(self, kind, X, lengthscale, scale=1.0, first=0, stride=1, store_dtype=None):
+    def sympack_elems(self, n, first=0, stride=1, store_dtype=torch.float32):
+        return int(self._lib.rk_sympack_elems(_DT[store_dtype], n, first, stride))
+
+    def sympack_materialize(self, kind, X, lengthscale, scale=1.0, first=0, stride=1, store_dtype=None, out=None):
         """Strip-packed upper triangle of scale * K(X, X) (strips first, first+stride, ...).
-        ``store_dtype=torch.float32`` with float64 X keeps the entries in float32."""
+        ``store_dtype=torch.float32`` with float64 X keeps the entries in float32.  ``out``: a 1-D buffer of the
+        storage dtype with at least ``sympack_elems`` entries to write into (its head is returned)."""
         dev, kid, X, ld, _X2, _ld2, ell, ell_vec, _i1, _i2, n, _n2 = self._kernel_common(
             kind, X, X, lengthscale, None, None
         )
         store_dtype = store_dtype or X.dtype
         elems = self._lib.rk_sympack_elems(_DT[store_dtype], n, first, stride)
-        Kp = torch.empty(max(elems, 1), dtype=store_dtype, device=dev)
+        if out is not None:
+            _req(out)
+            if out.dtype != store_dtype or out.ndim != 1 or out.numel() < elems or not out.is_contiguous():
+                raise ValueError("sympack_materialize: out must be a contiguous 1-D buffer of the storage dtype with room "
+                                 "for the packed strips")
+            Kp = out[: max(elems, 1)]
+        else:
+            Kp = torch.empty(max(elems, 1), dtype=store_dtype, device=dev)
         rc = self._lib.rk_kernel_materialize_sympack(
             _dt(X), _DT[store_dtype], kid, _ptr(X), n, ld, X.shape[1], ell, _ptr(ell_vec),
             float(scale), first, stride, _ptr(Kp), _stream(dev),

@@ -639,6 +639,19 @@ def test_matrix_free_operator_wide_product_uses_panels(be, monkeypatch, prec):
         M = torch.randn(n, cols, dtype=dt, generator=gen)
         got = A @ M.to(dev())
         assert rel_err(got.cpu(), K @ M.double()) < LIM[dt] * 5, cols
+    if dt == torch.float32:
+        # float32, symmetric data: the wide product above went through temporary cyclic strip subsets of the packed
+        # triangle + rk_symm_gemm (three subsets under this budget); the row-major panel route gives the same product
+        calls = []
+        real = be.symm_gemm
+        monkeypatch.setattr(be, "symm_gemm", lambda *a, **k: calls.append(k.get("stride")) or real(*a, **k))
+        M = torch.randn(n, 130, dtype=dt, generator=gen)
+        got = A @ M.to(dev())
+        assert len(calls) >= 2 and all(c == len(calls) for c in calls), calls
+        monkeypatch.setenv("RK_FREE_WIDE_STRIPS", "0")
+        panels = A @ M.to(dev())
+        assert rel_err(got.cpu(), K @ M.double()) < LIM[dt] * 5
+        assert rel_err(panels.cpu(), K @ M.double()) < LIM[dt] * 5
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 16, 17, 1000, 4097, 500_000])

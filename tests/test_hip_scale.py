@@ -484,3 +484,76 @@ def test_midsize_askotch_300_steps_match_oracle(accel):
           f"{[round(float(v), 5) for v in rel[:, 0]]}; oracle: {[round(float(v), 5) for v in want[:, 0]]}")
     torch.testing.assert_close(rel, want, rtol=2e-3, atol=0)
     assert float((W.cpu() - Wref).norm() / Wref.norm()) < 2e-3
+
+
+def test_fullsize_askotch_steps_match_oracle_rows():
+    """BASELINE config 5 at FULL size - n = 500 000, d = 50, k = 10, block 5 000 (n / 100), Nystrom rank 100, mu = reg =
+    1e-2, nu = 100, float32 (experiments/distributed_krr_linsys_askotch_solve_test.py:15-19,45-55 at n = 500 000) - for
+    20 whole accelerated steps: block preconditioner, power iteration, row-oracle gradient, iterate update.  Blocks,
+    test matrices and power-iteration starts are drawn once and fed to both sides; the oracle (oracle/sap.py =
+    rlaopt/solvers/sap.py:25-175) evaluates its row oracle with the C closed forms on the host (2.5e9 kernel entries
+    per step) and its block oracle densely.  Asserted: the rows of W the steps touched, and the whole iterate."""
+    from oracle import cbind
+    from oracle import sap as osap
+    from rlaopt_amd.kernels import DistributedRBFLinOp
+    from rlaopt_amd.solvers import SAPAccelConfig, SAPConfig
+    import rlaopt_amd.models.linsys as ml
+
+    n, d, k, blk_sz, rank, steps = 500_000, 50, 10, 5000, 100, 20
+    dt = torch.float32
+    g = torch.Generator().manual_seed(50)
+    X = (torch.randn(n, d, dtype=torch.float64, generator=g) / d**0.5).to(dt)
+    B = torch.randn(n, k, dtype=torch.float64, generator=g).to(dt)
+    reg, nu = 1e-2, 100.0
+    blocks = [torch.randperm(n, generator=g)[:blk_sz] for _ in range(steps)]
+    omegas = [(torch.randn(rank, blk_sz, dtype=torch.float64, generator=g) / rank**0.5).T.contiguous().to(dt)
+              for _ in range(steps)]
+    starts = [torch.randn(blk_sz, generator=g) for _ in range(steps)]
+
+    class Rows:  # K(X[blk], X) as an object supporting @ (matrix-free, host cores)
+        def __init__(self, blk):
+            self.Xb = X[blk].contiguous()
+
+        def __matmul__(self, V):
+            return cbind.kernel_matmat("rbf", self.Xb, X, 1.0, V.contiguous())
+
+    ref = osap.SAP(n, Rows, lambda blk: cbind.kernel_matrix("rbf", X[blk].contiguous(), X[blk].contiguous(), 1.0), B, reg,
+                   torch.zeros_like(B), ("nystrom", rank, reg, "gauss", True), blk_sz, accel=True, mu=reg, nu=nu,
+                   blk_sequence=blocks, omega_sequence=omegas, start_sequence=starts)
+    mask = torch.ones(k, dtype=torch.bool)
+    for _ in range(steps):
+        ref.step(mask)
+    # product
+    Xd = X.to(DEV)
+    A = DistributedRBFLinOp(Xd, Xd, KernelConfig(lengthscale=1.0), devices={DEV})
+    assert A.storage_mode == "matrix_free"  # (a 1 TB kernel matrix: the operator recomputes its entries)
+    system = LinSys(A, B.to(DEV), reg=reg, A_row_oracle=A.row_oracle, A_blk_oracle=A.blk_oracle)
+    cfg = SAPConfig(device=DEV, max_iters=steps, atol=0.0, rtol=1e-12,
+                    precond_config=NystromConfig(rank=rank, rho=reg, sketch="gauss"), blk_sz=blk_sz, accel=True,
+                    accel_config=SAPAccelConfig(mu=reg, nu=nu))
+    orig = ml._get_solver
+
+    def patched(model, W_init, solver_config):
+        s = orig(model=model, W_init=W_init, solver_config=solver_config)
+        s.inject_draws(blocks=[b.to(DEV) for b in blocks], starts=[v.to(DEV) for v in starts])
+        return s
+
+    ml._get_solver = patched
+    try:
+        with sketches.inject(*omegas):
+            W, log = system.solve(cfg, torch.zeros(n, k, dtype=dt, device=DEV), callback_freq=steps)
+    finally:
+        ml._get_solver = orig
+    assert sorted(log) == [0, steps]
+    W = W.cpu()
+    touched = torch.unique(torch.cat(blocks))
+    assert touched.numel() > 0.15 * n
+    err_rows = float((W[touched] - ref.W[touched]).norm() / ref.W[touched].norm())
+    err_all = float((W - ref.W).norm() / ref.W.norm())
+    print(f"\n[askotch full size] {steps} steps, {touched.numel()} rows touched: rel err of the touched rows {err_rows:.2e}, "
+          f"of W {err_all:.2e}; rel_res {float(log[steps]['metrics']['internal_metrics']['rel_res'].max()):.4f}")
+    assert err_rows < 2e-3 and err_all < 2e-3
+    untouched = torch.ones(n, dtype=torch.bool)
+    untouched[touched] = False
+    # (accelerated SAP moves W only on the blocks: W <- Y - eta d on the block, and Y = W elsewhere stays 0 from W_0 = 0)
+    assert float(W[untouched].abs().max()) <= 1e-6 + float(ref.W[untouched].abs().max())

@@ -42,7 +42,13 @@ def medians(trace_path):
 
 bench = json.loads([l for l in open(f"{src}/{tag}_bench_n1.log") if l.startswith("{")][-1])
 storage = bench["roofline"].get("storage", "materialize")
-KNAME = "symm_strip_kernel<float, float, 1>" if storage.startswith("sympack") else "skinny_nn_kernel<float, 1, 8"
+kdesc = bench["roofline"].get("kernel", "")
+if storage.startswith("sympack"):
+    KNAME = "symm_blk_h2_kernel" if "symm_blk_h2_kernel" in kdesc else "symm_strip_kernel<float, float, 1>"
+else:
+    KNAME = "skinny_nn_kernel<float, 1, 8"
+# the product's second launch (it reads the partial tables the first one wrote): its traffic belongs to the product
+FINISH = {"symm_blk_h2_kernel": "symm_blk_finish_kernel", "symm_strip_kernel<float, float, 1>": "symm_finish_kernel<float>"}.get(KNAME)
 
 
 def pmc(kind):
@@ -50,7 +56,10 @@ def pmc(kind):
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
             if KNAME in r["Kernel_Name"] and int(r["Grid_Size"]) > 100_000]
     big = [v for v in vals if v > 0.5 * max(vals)]  # the shard products, not the small U @ t ones
-    return sum(big) / len(big), len(big)
+    fin = [float(r["Counter_Value"]) for r in csv.DictReader(open(path))
+           if FINISH is not None and FINISH in r["Kernel_Name"]]
+    fin = [v for v in fin if v > 0.5 * max(fin)] if fin else []
+    return sum(big) / len(big) + (sum(fin) / len(fin) if fin else 0.0), len(big)
 
 
 trace = list(csv.DictReader(open(f"{src}/{tag}_prof/{tag}_kernel_trace.csv")))
