@@ -284,7 +284,7 @@ class _KernelBlock:
         matrix cores': n = 200 000, r = 512: see DESIGN.md (0.77 s through panels)."""
         be = get_backend()
         n = self.A1.shape[0]
-        budget = _FREE_PANEL_BYTES
+        budget = 2 * _FREE_PANEL_BYTES  # (16 GB: five subsets at n = 200 000; every subset's product ends in a ~6 ms tail)
         if x.is_cuda:
             budget = min(budget, int(0.5 * torch.cuda.mem_get_info(x.device)[0]))
         parts = max(1, -(-(n * n * 2 + n * 1024) // max(budget, 1)))  # packed float32 triangle = 2 n^2 bytes (+ diagonal blocks)
@@ -508,17 +508,20 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
         devs = _sorted_devices(devices)
         rank, size = _dist.world(group)
         spmd = _dist.spmd_active(group)
-        if not spmd and len({(d.type, d.index) for d in devs if d.type == "cuda"}) > 1:
-            # the reference's own multi-GPU call (one process, devices={cuda:0 .. cuda:p-1},
-            # rlaopt/kernels/factory.py:34-41) is accepted, but it is not the layout this engine is built for
+        # the reference's own multi-GPU call: one process, devices={cuda:0 .. cuda:p-1} (rlaopt/kernels/factory.py:34-41)
+        self._inprocess_multi_device = (not spmd
+                                        and len({(d.type, d.index) for d in devs if d.type == "cuda"}) > 1)
+        if self._inprocess_multi_device:
             import warnings
 
             warnings.warn(
-                f"rlaopt_amd: {len(devs)} devices in ONE process: the shards are driven from this process's launch "
-                "queues one after another, without the strip-packed symmetric storage and without RCCL, and this "
-                "mode has never run on more than one physical GPU.  For multi-GPU runs start one rank per GPU "
-                "(python -m torch.distributed.run --nproc-per-node P script.py, torch.distributed.init_process_group"
-                "('nccl')) and pass this rank's device: the operator then shards itself over the process group.",
+                f"rlaopt_amd: {len(devs)} devices in ONE process.  LinSys.solve runs such a system as one fresh worker "
+                "process per device (rlaopt_amd/spmd.py: one rank per GPU over RCCL, strip-packed storage, state "
+                "row-partitioned) and returns rank 0's result - unless a user callback or RK_MULTI_DEVICE=inprocess "
+                "asks for the in-process form, whose shards are driven from this process's launch queues one after "
+                "another, without the packed storage and without RCCL.  Neither form has run on more than one physical "
+                "GPU yet.  Scripts that start one rank per GPU themselves (python -m torch.distributed.run "
+                "--nproc-per-node P ...) pass this rank's device: the operator then shards itself over the group.",
                 RuntimeWarning, stacklevel=3)
         parts = size if spmd else len(devs)
         n1, n2 = A1.shape[0], A2.shape[0]

@@ -10,6 +10,7 @@ SPMD operator, ``A @ X`` for any other operator - so that the solvers are writte
 
 from __future__ import annotations
 
+import os
 from typing import Any, Callable
 
 import torch
@@ -168,6 +169,19 @@ class LinSys(Model):
         _is_torch_tensor(W_init, "W_init")
         if log_in_wandb and wandb_init_kwargs is None:
             raise ValueError("wandb_init_kwargs must be specified if log_in_wandb is True")
+        if (getattr(self._A, "_inprocess_multi_device", False) and callback_fn is None and not log_in_wandb
+                and os.environ.get("RK_MULTI_DEVICE", "spmd") != "inprocess"):
+            # one process naming several GPUs (the reference's own call): run the solve as one fresh worker process
+            # per device - the one-rank-per-GPU layout this engine is built for - and hand back rank 0's result
+            from .. import spmd
+
+            own_oracles = (self._A_row_oracle is not None
+                           and getattr(self._A_row_oracle, "__self__", None) is self._A
+                           and getattr(self._A_blk_oracle, "__self__", None) is self._A)
+            if self._A_row_oracle is None or own_oracles:
+                W, log = spmd.solve_kernel_system(self._A, self._B, self._reg, solver_config, W_init,
+                                                  callback_freq=callback_freq, with_oracles=own_oracles)
+                return W.to(W_init.device), log
         _dist.reset_seed_stream()  # (one rank per GPU: this solve's draws follow rank 0's generator as of now)
         atol, rtol = solver_config.atol, solver_config.rtol
         logger = Logger(

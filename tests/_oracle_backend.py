@@ -121,3 +121,10 @@ class OracleBackend:
     def randn(self, rows, cols, dtype, device, seed, offset=0, scale=1.0):
         g = torch.Generator().manual_seed((int(seed) * 1000003 + int(offset)) % (2**63))
         return scale * torch.randn(rows, cols, dtype=dtype, generator=g).to(device)
+
+
+def install_for_worker():
+    """``init`` hook of ``rlaopt_amd.spmd.run`` in the CPU tests: every worker process computes with the oracle."""
+    import rlaopt_amd.ops as ops
+
+    ops._backend = OracleBackend()

@@ -632,7 +632,8 @@ def test_matrix_free_operator_wide_product_uses_panels(be, monkeypatch, prec):
     gen = torch.Generator().manual_seed(4)
     n, d = 700, 9
     X = (torch.randn(n, d, dtype=dt, generator=gen) / d**0.5)
-    A = RBFLinOp(X.to(dev()), X.to(dev()), KernelConfig(lengthscale=1.1, const_scaling=0.7))
+    Xd = X.to(dev())
+    A = RBFLinOp(Xd, Xd, KernelConfig(lengthscale=1.1, const_scaling=0.7))
     assert A.storage_mode == "matrix_free"
     K = ok.kernel_matrix("rbf", X.double(), X.double(), 1.1, 0.7)
     for cols in (3, 130):

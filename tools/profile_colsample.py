@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--d", type=int, default=64)
     ap.add_argument("--rank", type=int, default=512)
     ap.add_argument("--sketch", default="colsample")
+    ap.add_argument("--cprofile", action="store_true", help="host-side call profile of one more assembly")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     be = get_backend()
@@ -66,5 +67,37 @@ def main():
             print(f"    {name:40s} {t:8.2f} ms")
 
 
+def cprofile_pass(args):
+    import cProfile
+    import pstats
+
+    dev = torch.device("cuda:0")
+    n, d, r = args.n, args.d, args.rank
+    X, _B, _Om = make_problem(n, d, 8, torch.float32)
+    Xd = X.to(dev)
+    A = DistributedRBFLinOp(Xd, Xd, KernelConfig(lengthscale=1.0), devices={dev})
+    A.local_matmat(torch.zeros(n, 1, device=dev))
+    for rep in range(2):
+        P = Nystrom(NystromConfig(rank=r, rho=1e-6 * n, sketch=args.sketch, damping_mode="adaptive"))
+        pr = cProfile.Profile()
+        torch.cuda.synchronize()
+        pr.enable()
+        P._update(A, dev)
+        P._update_damping(baseline_rho=1e-6 * n)
+        torch.cuda.synchronize()
+        pr.disable()
+        if rep == 1:
+            pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
+
+
 if __name__ == "__main__":
+    if "--cprofile" in sys.argv:
+        ap = argparse.ArgumentParser()
+        ap.add_argument("--n", type=int, default=200000)
+        ap.add_argument("--d", type=int, default=64)
+        ap.add_argument("--rank", type=int, default=512)
+        ap.add_argument("--sketch", default="colsample")
+        ap.add_argument("--cprofile", action="store_true")
+        cprofile_pass(ap.parse_args())
+        sys.exit(0)
     main()
