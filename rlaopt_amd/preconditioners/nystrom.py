@@ -64,12 +64,15 @@ def _inv_sqrt_near_identity(G: torch.Tensor) -> torch.Tensor:
     r x r products instead of an eigen-decomposition (0.7 ms on the host at r = 100, the largest
     single cost of a block preconditioner).  Rank-deficient or far-from-orthonormal input takes
     the eigen-decomposition, which also drops the null directions."""
-    r = G.shape[0]
-    E = G - torch.eye(r, dtype=G.dtype)
+    # (no torch.eye here: outside a small_host_lapack context it runs on the host-wide thread pool - 17 ms per call
+    # for a 512 x 512 identity on a GPU box, a third of the whole assembly)
+    E = G.clone()
+    E.diagonal().sub_(1.0)
     if float(torch.linalg.matrix_norm(E)) <= 1e-3:
         E2 = E @ E
-        return (torch.eye(r, dtype=G.dtype) - 0.5 * E + 0.375 * E2 - 0.3125 * (E2 @ E)
-                + (35.0 / 128.0) * (E2 @ E2))
+        out = -0.5 * E + 0.375 * E2 - 0.3125 * (E2 @ E) + (35.0 / 128.0) * (E2 @ E2)
+        out.diagonal().add_(1.0)
+        return out
     w, Q = torch.linalg.eigh(G)
     inv_sqrt = torch.where(w > 1e-8, w.clamp_min(1e-300).rsqrt(), torch.zeros_like(w))
     return (Q * inv_sqrt[None, :]) @ Q.T
@@ -159,7 +162,8 @@ class Nystrom(Preconditioner):
         be = get_backend()
         rank_r = self.config.rank
         shift = torch.finfo(dtype).eps * torch.trace(core)  # eps of the WORKING dtype
-        core = core + shift * torch.eye(rank_r, dtype=torch.float64)
+        core = core.clone()
+        core.diagonal().add_(shift)
         with small_host_lapack(rank_r):
             L = torch.linalg.cholesky(core, upper=False)
             H = torch.linalg.solve_triangular(L, gram, upper=False)

@@ -628,7 +628,7 @@ def test_matrix_free_operator_wide_product_uses_panels(be, monkeypatch, prec):
 
     dt = DTYPES[prec]
     monkeypatch.setenv("RK_KERNEL_MODE", "matrix_free")
-    monkeypatch.setattr(kb, "_FREE_PANEL_BYTES", 300 * 700 * 8)  # ~300 rows per panel
+    monkeypatch.setattr(kb, "_FREE_PANEL_BYTES", 300 * 700 * 4)  # ~300 rows per row-major panel, two strip subsets
     gen = torch.Generator().manual_seed(4)
     n, d = 700, 9
     X = (torch.randn(n, d, dtype=dt, generator=gen) / d**0.5)
