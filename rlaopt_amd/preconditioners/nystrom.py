@@ -70,9 +70,9 @@ def _inv_sqrt_near_identity(G: torch.Tensor) -> torch.Tensor:
     E.diagonal().sub_(1.0)
     if float(torch.linalg.matrix_norm(E)) <= 1e-3:
         E2 = E @ E
-        out = -0.5 * E + 0.375 * E2 - 0.3125 * (E2 @ E) + (35.0 / 128.0) * (E2 @ E2)
-        out.diagonal().add_(1.0)
-        return out
+        out = -0.5 * E
+        out.diagonal().add_(1.0)  # I - E/2, then the remaining terms in the series' order
+        return out + 0.375 * E2 - 0.3125 * (E2 @ E) + (35.0 / 128.0) * (E2 @ E2)
     w, Q = torch.linalg.eigh(G)
     inv_sqrt = torch.where(w > 1e-8, w.clamp_min(1e-300).rsqrt(), torch.zeros_like(w))
     return (Q * inv_sqrt[None, :]) @ Q.T
