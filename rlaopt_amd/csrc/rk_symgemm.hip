@@ -38,7 +38,11 @@
 // with four waves, one per SIMD, the matrix cores were busy 39 % of the time), each 32 rows x TN / 2 columns
 // = 2 x NCB accumulator blocks of v_mfma_f32_16x16x32_{f16,bf16}.  Measured and not kept (A/B on one box, 121.0 ms):
 // s_setprio 1 for waves 4 - 7 (120.8 ms), sched_group_barrier interleaving of operand reads and matrix-core
-// instructions (122.2 ms).
+// instructions (122.2 ms).  Round 4: staggering the two waves of a SIMD (waves 4 - 7 do a step's arithmetic first and
+// its staging second; legal, the staging writes the other buffer) - as a branch inside the loop 294 ms (the compiler
+// drains the prefetch queue at the joins), as two copies of the loop chosen once per phase 223 ms against 122 ms (a
+// rank's partial at p = 8: 37.9 against 20.9 ms): two different instruction streams per CU and later load issue for
+// half the waves cost far more than the lockstep it removes.
 #include <atomic>
 #include <stdlib.h>
 
