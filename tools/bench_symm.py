@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Strip-packed symmetric product ``rk_symm_matmat`` for 1 .. 16 right-hand sides on one MI355X:
-ms per product and GB/s of packed bytes; float32: the float16-split kernel on the 16-bit matrix cores (f16x2) against
-the float32 matrix-core strip kernel (wide) and groups of 4 through the register kernel (RK_SYMM_WIDE=0)."""
+ms per product and GB/s of packed bytes; float32: the block kernel on the 16-bit matrix cores (f16x2: four strips side by
+side per work item, round 4) against round 3's strip form of it (f16x2_strip), the float32 matrix-core strip kernel
+(wide), groups of 4 through the register kernel (RK_SYMM_WIDE=0) and, for k <= 4, the register kernel."""
 import argparse
 import json
 import os
@@ -21,6 +22,8 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--check-rows", type=int, default=1024, help="rows compared with a float64 product (0: none)")
+    ap.add_argument("--modes", default="", help="comma list restricting the kernels timed (f16x2,wide,groups_of_4,register,"
+                                                "f16x2_strip); f16x2 = the block kernel, f16x2_strip = round 3's strip kernel")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     be = get_backend()
@@ -36,14 +39,22 @@ def main():
         outs = {}
         modes = ["f16x2", "wide", "groups_of_4"] if args.dtype == "f32" else ["wide", "groups_of_4"]
         if k <= 4:
-            modes = ["register", "f16x2"] if (args.dtype == "f32" and k >= 2) else ["register"]
+            modes = ["register", "f16x2"] if args.dtype == "f32" else ["register"]
+        if args.dtype == "f32":
+            modes.append("f16x2_strip")
+        if args.modes:
+            modes = [m for m in modes if m in args.modes.split(",")]
         # (the accuracy check - float64 GEMMs - runs AFTER the timing of this k: right behind it the matrix-core /
         # LDS-staged kernels measured 8 - 15 % slower, the HBM-bound k = 1 kernel the same: clock state)
         for mode in modes:
             os.environ["RK_SYMM_WIDE"] = "0" if mode == "groups_of_4" else "1"
             os.environ["RK_SYMM_F16X2_MIN"] = "1"
             os.environ["RK_SYMM_F16X2_MIN_BYTES"] = "0"
-            kmax = 1.0 if mode == "f16x2" else None
+            kmax = 1.0 if mode.startswith("f16x2") else None
+            if mode == "f16x2_strip":
+                os.environ["RK_SYMM_H2_IMPL"] = "strip"
+            else:
+                os.environ.pop("RK_SYMM_H2_IMPL", None)
             _sm = be.symm_matmat
             be_symm = lambda Kp_, n_, V_: _sm(Kp_, n_, V_, kmax=kmax)  # noqa: E731
             Y = be_symm(Kp, n, V)
@@ -64,6 +75,7 @@ def main():
                 rec[mode]["max_col_err_vs_f64"] = float(((Y[rows].double() - want).norm(dim=0) / want.norm(dim=0)).max())
             del want
         os.environ["RK_SYMM_WIDE"] = "1"
+        os.environ.pop("RK_SYMM_H2_IMPL", None)
         os.environ.pop("RK_SYMM_F16X2_MIN", None)
         os.environ.pop("RK_SYMM_F16X2_MIN_BYTES", None)
         print(json.dumps(rec), flush=True)

@@ -3,14 +3,16 @@
 # Usage (on the box, from the repo root): bash tools/gpu_round.sh <tag>
 set -o pipefail
 TAG=${1:-r01}
-PART=${2:-all}   # a: tests, bench, rocprof / PMC of the bench; b: everything else; all: both (needs > 20 minutes)
+PART=${2:-all}   # a: tests, bench, rocprof / PMC of the bench; b: the other benches; c: round-4 additions (packed multi-RHS
+                 # PMC, write-cost probe, float64 lines, self-launched two-rank rehearsal); all: everything (> 30 minutes)
 OUT=gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 if [ "$PART" != "b" ]; then
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/${TAG}_smoke.log 2>&1; tail -1 $OUT/${TAG}_smoke.log
 timeout -k 10 800 python -m pytest tests -m gpu -q -x > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest EXIT $?"; tail -3 $OUT/${TAG}_pytest_gpu.log
-timeout -k 10 300 python bench.py > $OUT/${TAG}_bench_n1.log 2>&1 && echo "bench ok" && tail -1 $OUT/${TAG}_bench_n1.log | cut -c1-400
+# (the driver's exact command line)
+timeout -k 10 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_n1.log 2>$OUT/${TAG}_bench_n1.err && echo "bench ok" && tail -1 $OUT/${TAG}_bench_n1.log | cut -c1-400
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -o ${TAG} -- python3 bench.py --no-cpu-baseline --no-solve > $OUT/${TAG}_bench_under_rocprof.log 2>&1 && echo "rocprof stats ok"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o ${TAG} -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-solve > $OUT/${TAG}_pmc_fetch.log 2>&1 && echo "pmc fetch ok"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o ${TAG} -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-solve > $OUT/${TAG}_pmc_write.log 2>&1 && echo "pmc write ok"
@@ -18,6 +20,20 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_mfma -o ${TAG} -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-solve > $OUT/${TAG}_pmc_mfma.log 2>&1 && echo "pmc mfma ok"
 fi
 if [ "$PART" = "a" ]; then exit 0; fi
+if [ "$PART" = "c" ] || [ "$PART" = "all" ]; then
+# packed symmetric product, 1 .. 16 right-hand sides: block kernel vs round 3's strip kernel vs the float32 kernels
+timeout -k 10 400 python3 tools/bench_symm.py --ks 1,2,4,5,8,10,16 > $OUT/${TAG}_bench_symm.log 2>&1 && echo "symm ok"
+bash tools/pmc_symm.sh ${TAG} > $OUT/${TAG}_pmc_symm.log 2>&1 && python3 tools/pmc_symm_table.py $OUT/${TAG}_symm_pmc > $OUT/${TAG}_symm_pmc_table.md && echo "pmc symm ok"
+timeout -k 10 300 tools/_build/wr_probe 40 > $OUT/${TAG}_wr_probe.log 2>&1 && echo "wr probe ok"
+# float64 secondary lines: float64 storage, and float64 iteration over float32 storage
+timeout -k 10 500 python3 bench.py --dtype f64 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_f64.log 2>/dev/null && echo "f64 ok"
+timeout -k 10 400 python3 bench.py --dtype f64 --storage f32 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_f64_f32storage.log 2>/dev/null && echo "f64/f32 ok"
+# the multi-rank entry as the driver would call it: bench.py starts its own ranks (two gloo ranks on this one GPU)
+RK_BENCH_BACKEND=gloo RK_BENCH_ONE_GPU=1 timeout -k 10 500 python3 bench.py --gpus 2 --steps 20 --warmup 5 > $OUT/${TAG}_bench_gloo_world2_selflaunch.log 2>$OUT/${TAG}_bench_gloo_world2_selflaunch.err && echo "self-launched world 2 ok"
+timeout -k 10 200 python3 tools/profile_colsample.py > $OUT/${TAG}_profile_colsample.log 2>&1 && echo "colsample profile ok"
+timeout -k 10 200 python3 tools/profile_colsample.py --sketch gauss > $OUT/${TAG}_profile_gauss.log 2>&1 && echo "gauss profile ok"
+if [ "$PART" = "c" ]; then exit 0; fi
+fi
 # the two "next" rows of SURVEY 8(f): ASkotch (config 5) and LSQR (config 4)
 timeout -k 10 300 python3 tools/bench_sap.py > $OUT/${TAG}_bench_sap.log 2>&1 && echo "sap ok" && tail -1 $OUT/${TAG}_bench_sap.log | cut -c1-300
 timeout -k 10 300 python3 tools/bench_lsqr.py > $OUT/${TAG}_bench_lsqr.log 2>&1 && echo "lsqr ok" && tail -1 $OUT/${TAG}_bench_lsqr.log | cut -c1-300
@@ -28,7 +44,6 @@ timeout -k 10 300 python3 tools/bench_kmatmat.py > $OUT/${TAG}_bench_kmatmat.log
 timeout -k 10 300 python3 tools/bench_kmatmat.py --kind matern32 --modes bf16x3,direct --cases 100000x100000x64x1,100000x100000x64x4,5000x500000x50x4g,5000x500000x50x10g >> $OUT/${TAG}_bench_kmatmat.log 2>&1 && echo "kmatmat matern ok"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_kmatmat -o ${TAG} -- python3 tools/bench_kmatmat.py --modes bf16x3 --reps 2 --cases 200000x200000x64x1,200000x200000x32x1,5000x500000x50x10g > $OUT/${TAG}_pmc_kmatmat.log 2>&1 && echo "pmc kmatmat ok"
 # many right-hand sides: packed symmetric and row-major streaming kernels
-timeout -k 10 300 python3 tools/bench_symm.py > $OUT/${TAG}_bench_symm.log 2>&1 && echo "symm ok"
 timeout -k 10 300 python3 tools/bench_skinny.py > $OUT/${TAG}_bench_skinny.log 2>&1 && timeout -k 10 300 python3 tools/bench_skinny.py --f64 >> $OUT/${TAG}_bench_skinny.log 2>&1 && echo "skinny ok"
 timeout -k 10 200 python3 tools/bench_dense_c1.py > $OUT/${TAG}_bench_dense_c1.log 2>&1 && echo "dense c1 ok" && tail -1 $OUT/${TAG}_bench_dense_c1.log | cut -c1-200
 # storage-free PCG (matrix-free operator, symmetric evaluation)
