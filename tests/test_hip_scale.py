@@ -221,6 +221,12 @@ def test_fullsize_packed_symmetric_product(be, full_problem):
     # one right-hand side, and symmetry of the bilinear form through the packed operator
     y1 = be.symm_matmat(Kp, n, vd[:, 0].contiguous(), diag_shift=reg)
     assert float((y1 - y[:, 0]).norm() / y[:, 0].norm()) < 1e-5
+    # the same column through the block kernel on the 16-bit matrix cores - what the PCG loop runs at this size (the
+    # operator passes the bound on its entries): the float32 kernel's result, the oracle's rows, bit for bit repeatable
+    y1h = be.symm_matmat(Kp, n, vd[:, 0].contiguous(), diag_shift=reg, kmax=1.0)
+    assert torch.equal(y1h, be.symm_matmat(Kp, n, vd[:, 0].contiguous(), diag_shift=reg, kmax=1.0))
+    assert float((y1h - y1).norm() / y1.norm()) < 1e-5
+    assert float((y1h[rows.to(DEV)].cpu() - want[:, 0]).norm() / want[:, 0].norm()) < 2e-5
     ud = u.to(DEV)
     Ku = be.symm_matmat(Kp, n, ud)
     Kv = y - reg * vd
@@ -272,6 +278,32 @@ def test_fullsize_packed_symmetric_product(be, full_problem):
     assert float((total - Kv).norm() / Kv.norm()) < 1e-5
     assert float((total6.double() - Yg[:, :6].double()).norm() / Yg[:, :6].double().norm()) < 1e-5
     assert float((totalg.double() - Yg.double()).norm() / Yg.double().norm()) < 1e-5
+
+
+def test_fullsize_matrix_free_sketch_product(be, full_problem, monkeypatch):
+    """RK_KERNEL_MODE=matrix_free at the BASELINE size: a product with many columns (the Nystrom sketch) runs without
+    n x n storage - cyclic strip subsets of the packed triangle in one 16 GB temporary + rk_symm_gemm on the 16-bit
+    matrix cores, partials added.  Sampled rows against the float64 C oracle; a narrow product of the same operator
+    (the fused matrix-free kernel) agrees on the shared columns."""
+    X, _u, v = full_problem
+    n = X.shape[0]
+    Xd = X.to(DEV)
+    monkeypatch.setenv("RK_KERNEL_MODE", "matrix_free")
+    A = RBFLinOp(Xd, Xd, KernelConfig(lengthscale=1.0))
+    assert A.storage_mode == "matrix_free"
+    g = torch.Generator().manual_seed(12)
+    Om = torch.cat([v.to(DEV), torch.randn(n, 128, generator=g).to(DEV) / 128**0.5], dim=1)
+    torch.cuda.reset_peak_memory_stats()
+    before = torch.cuda.memory_allocated()
+    Y = A @ Om
+    assert torch.cuda.max_memory_allocated() - before < 20e9  # one 16 GB subset buffer, not the 80 GB triangle
+    rows = torch.tensor([0, 255, 256, 100000, 199680, 199999])
+    want = cbind.kernel_matmat("rbf", X[rows].double(), X.double(), 1.0, Om.cpu().double())
+    err = float((Y[rows.to(DEV)].cpu().double() - want).norm() / want.norm())
+    assert err < 1e-5, err
+    narrow = A @ v.to(DEV)
+    k = v.shape[1]
+    assert float((Y[:, :k] - narrow).norm() / narrow.norm()) < 1e-5
 
 
 def test_fullsize_lsqr_recovers_planted_solution():
