@@ -153,8 +153,11 @@ class Nystrom(Preconditioner):
         return Y, host[0], host[1], (host[2] if sk.raw else None)
 
     def _update(self, A, device, before_host_wait=None):
-        Y, core, gram, _ = self._sketch_and_grams(A, device, before_host_wait)
-        self._finish_spectral(Y, core, gram, A.dtype, device)
+        from ..utils import quiet_host
+
+        with quiet_host():  # (a stable, small host thread pool for the r x r algebra; re-entrant inside a solve)
+            Y, core, gram, _ = self._sketch_and_grams(A, device, before_host_wait)
+            self._finish_spectral(Y, core, gram, A.dtype, device)
 
     def _finish_spectral(self, Y, core, gram, dtype, device):
         """U, S of the rank-r approximation from the Gram blocks (the reference's thin SVD of B^T,

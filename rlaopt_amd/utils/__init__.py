@@ -55,7 +55,10 @@ def small_host_lapack(order: int):
     threads of a GPU host is ~100x slower than with one (measured: 156 ms vs ~1 ms per eigh)."""
     want = 1 if order <= 256 else (4 if order <= 1024 else 16)
     prev = _torch.get_num_threads()
-    if prev > want:
+    # (only when the pool is far too wide: every change of the thread count makes the next parallel region rebuild its
+    # team - a 512 x 512 Cholesky was measured at 66 ms instead of 2 ms right after a switch; inside quiet_host's
+    # 8-thread pool an order-512 factorisation simply keeps the 8 threads)
+    if prev > 2 * want:
         _torch.set_num_threads(want)
     try:
         yield

@@ -32,11 +32,15 @@ def test_quiet_host_limits_and_restores_threads():
             assert torch.get_num_threads() == min(outer, 2)
             with quiet_host(max_threads=1):  # nested: the outermost context decides
                 assert torch.get_num_threads() == min(outer, 2)
-                with small_host_lapack(64):
-                    assert torch.get_num_threads() == 1
+                with small_host_lapack(64):  # (a pool at most twice the wanted size is left alone: no team rebuild)
+                    assert torch.get_num_threads() == min(outer, 2)
                 assert torch.get_num_threads() == min(outer, 2)
             assert torch.get_num_threads() == min(outer, 2)
         assert torch.get_num_threads() == outer
+        if outer > 2:
+            with small_host_lapack(64):  # far too wide for a 64 x 64 factorisation: one thread
+                assert torch.get_num_threads() == 1
+            assert torch.get_num_threads() == outer
         with pytest.raises(RuntimeError):
             with quiet_host(max_threads=2):
                 raise RuntimeError("boom")
