@@ -281,7 +281,9 @@ class _KernelBlock:
         f, f + P, ... - the layout a rank of a P-rank run holds) and each subset's partial of K x comes from the
         16-bit matrix cores (``rk_symm_gemm``); the partials add up.  Every entry is evaluated once (the row-major
         panels evaluate the full square) and the product runs at the sketch kernel's rate instead of the float32
-        matrix cores': n = 200 000, r = 512: see DESIGN.md (0.77 s through panels)."""
+        matrix cores': n = 200 000, r = 512: see DESIGN.md (0.77 s through panels).  Writing subset f + 1 on a second
+        stream beside subset f's product (two buffers) was measured: 0.29 against 0.26 s for the assembly - the two
+        kernels compete for the same CUs; not kept."""
         be = get_backend()
         n = self.A1.shape[0]
         budget = 2 * _FREE_PANEL_BYTES  # (16 GB: five subsets at n = 200 000; every subset's product ends in a ~6 ms tail)
