@@ -193,8 +193,15 @@ with open(f"{dst}/{tag}_summary.md", "w") as f:
                         ("symgemm_sq_counters", "SQ counters of the sketch kernel (tools/pmc_symgemm.sh)"),
                         ("sap_solve", "ASkotch end to end: tools/bench_sap.py --solve (300 iterations, callback_freq 100)"),
                         ("bench_gloo_world2", "Two gloo ranks on one GPU: the multi-rank path of bench.py (n = 100 000)"),
+                        ("bench_gloo_world2_selflaunch", "`RK_BENCH_BACKEND=gloo RK_BENCH_ONE_GPU=1 python3 bench.py --gpus 2`: bench.py starts its own ranks"),
+                        ("symm_pmc_table", "Packed symmetric product (block kernel + finishing kernel): HBM traffic and matrix-core busy per k (tools/pmc_symm.sh)"),
+                        ("wr_probe", "What stores cost beside a streaming read (tools/wr_probe.hip)"),
+                        ("bench_f64", "Secondary line: bench.py --dtype f64 (float64 storage, 160 GB packed)"),
+                        ("bench_f64_f32storage", "Secondary line: bench.py --dtype f64 --storage f32 (float64 iteration over the float32 triangle)"),
+                        ("profile_colsample", "Nystrom assembly with the column-sampling sketch by stage (tools/profile_colsample.py)"),
+                        ("profile_gauss", "Nystrom assembly with the Gaussian sketch by stage (tools/profile_colsample.py --sketch gauss)"),
                         ("host_probe", "Host of the box (tools/host_probe.py)")):
-        ext = "txt" if name.endswith("counters") else "log"
+        ext = "txt" if name.endswith("counters") else ("md" if name.endswith("table") else "log")
         blog = f"{src}/{tag}_{name}.{ext}"
         if not os.path.exists(blog):
             continue
@@ -205,6 +212,11 @@ with open(f"{dst}/{tag}_summary.md", "w") as f:
                 continue
             f.write(l[:600].rstrip() + "\n")
         f.write("```\n\n")
+    for name in ("smoke", "pytest_gpu"):
+        blog = f"{src}/{tag}_{name}.log"
+        if os.path.exists(blog):
+            tail = [l.rstrip() for l in open(blog) if l.strip()][-2:]
+            f.write(f"## {name}\n\n```\n" + "\n".join(t[:300] for t in tail) + "\n```\n\n")
     f.write("## HBM traffic of the shard product (separate --pmc passes)\n\n")
     f.write(f"FETCH_SIZE = {fetch:.0f} KB, WRITE_SIZE = {write:.0f} KB per launch -> "
             f"(2 x FETCH + WRITE) x 1024 = {traffic / 1e9:.2f} GB vs algorithmic {algo / 1e9:.2f} GB "
