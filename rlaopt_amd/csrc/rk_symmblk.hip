@@ -92,22 +92,40 @@ static int64_t blk_items(const BlkLayout& B) {
     return total;
 }
 
-// Rows per item.  Taller items shrink the (item, column) table (k floats per column and item), but the persistent grid
-// needs enough items per workgroup for an even finish (items are claimed dynamically: the tail is at most one item long):
-// the tallest of 2048 / 1024 / 512 / 256 that still gives every CU ~24 items (n = 200 000 on one GPU: 2048; its 1/8
-// shard of an 8-rank run: 512).
+// Rows per item.  Taller items shrink the (item, column) table (k floats per column and item) and amortise the per-item
+// fixed costs (the group's V into LDS, one pipeline fill, the table flush: about 40 rows' worth of streaming), but the
+// persistent grid runs ceil(items / CUs) rounds of items and the last round is rarely full: H is the multiple of 32 in
+// [256, 2048] that minimises rounds x (H + 40) among those that leave every CU at least 12 items (items are claimed
+// dynamically, so rounds are approximate: the tail is at most one item long).  n = 200 000 on one GPU (256 CUs): see
+// profiles/r04_ab_symm.log.  The choice is cached per (n, first, stride, CUs).
+static int pick_item_rows(BlkLayout B, int64_t cus) {
+    struct Key { int64_t n, first, stride, cus; int h; };
+    static thread_local Key cache[8] = {};
+    for (const Key& c : cache)
+        if (c.h && c.n == B.L.n && c.first == B.L.first && c.stride == B.L.stride && c.cus == cus) return c.h;
+    double best = 1e300;
+    int best_h = 256;
+    for (int h = 2048; h >= 256; h -= 32) {
+        B.H = h;
+        const int64_t items = blk_items(B);
+        if (items < 12 * cus && h > 256) continue;
+        const double cost = (double)ceil_div(items, cus) * (h + 40);
+        if (cost < best) { best = cost; best_h = h; }
+    }
+    static thread_local int next = 0;
+    cache[next] = Key{B.L.n, B.L.first, B.L.stride, cus, best_h};
+    next = (next + 1) % 8;
+    return best_h;
+}
+
 static BlkLayout make_blk_layout(int64_t n, int64_t first, int64_t stride, int64_t cus = 256) {
     BlkLayout B;
     B.L = make_layout<float>(n, first, stride);
     B.T_loc = B.L.strips_local();
     B.Q = ceil_div(B.T_loc, B2_G);
     B.H = B2_H_FIXED;
-    if (B2_H_FIXED == 0) {
-        for (int h : {2048, 1024, 512, 256}) {
-            B.H = h;
-            if (blk_items(B) >= 24 * cus) break;
-        }
-    }
+    B.max_chunks = 0;
+    if (B2_H_FIXED == 0) B.H = B.Q > 0 ? pick_item_rows(B, cus) : 256;
     B.max_chunks = ceil_div(n, B.H);
     return B;
 }
