@@ -187,6 +187,21 @@ int rk_symm_gemm(const void* Kp, int64_t n, int64_t strip_first, int64_t strip_s
                  const void* V, int64_t k, int64_t ldv, double alpha, void* Y, int64_t ldy, void* ws,
                  size_t ws_bytes, void* stream);
 
+/* The same wide product for an operator that stores NOTHING (matrix-free): Y (n1 x k) = alpha * scale *
+ * K(X1, X2) V for up to 1024 columns - Y = A @ Omega of rlaopt/preconditioners/nystrom.py:79 as the reference itself
+ * forms it, matrix-free (rlaopt/kernels/base.py:43-44,58-59: a pykeops reduction per call).  The kernel entries are
+ * evaluated tile by tile inside the product (X2 tile x X1 rows on the 16-bit matrix cores, the kernel function on the
+ * accumulators, split, straight into the operand image of the main product): no n x n storage, no temporary panels.
+ * float32, d <= 64, kind in {RK_RBF, RK_MATERN32, RK_MATERN52}; `center` (d floats, device) is REQUIRED and the caller
+ * vouches for max |(x - center) / ell|^2 <= RK_GRAM_MAX_NORM2 over both point sets, exactly as for the matrix-core
+ * form of rk_kernel_matmat (rk_kernel_center / rk_kernel_gram_bound).  X1 == X2 (same pointer, size, stride) shares
+ * one image.  Overwrites Y. */
+size_t rk_kernel_sketch_ws_bytes(int64_t n1, int64_t n2, int64_t k);
+int rk_kernel_sketch_matmat(int kind, const void* X1, int64_t n1, int64_t ldx1, const void* X2, int64_t n2,
+                            int64_t ldx2, int64_t d, double ell_scalar, const void* ell_vec, const void* center,
+                            double scale, const void* V, int64_t k, int64_t ldv, double alpha, void* Y, int64_t ldy,
+                            void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Transport  [a5, e]: RCCL behind the C ABI, one communicator per rank (one rank per GPU).
  * Replaces the reference's worker processes, pickled task / result queues and host staging

@@ -720,6 +720,15 @@ size_t bx_x2_image_bytes(int64_t n2, int64_t d) {
 
 void gram_prep_launch(const float* center, const float* ell_vec, int64_t d, float* iw, float* muw, hipStream_t st);
 
+// the split images of a point set (d <= 64; 64 points per 16 KiB image) and |x'|^2, for other translation units
+// (rk_symgemm.hip: the fused sketch product of matrix-free operators)
+void gram_split64_launch(const float* X, int64_t ldx, const int64_t* idx, int64_t n, int64_t npad, int64_t d,
+                         const float* iw, const float* muw, unsigned char* img, float* norms, hipStream_t st) {
+    static_assert(RK_BX_F16X2 == 1 && BX_IMG == 16384 && BX_SPLIT == 8192, "rk_symgemm.hip reads this image format");
+    hipLaunchKernelGGL(gram_split_kernel<64>, dim3((unsigned)ceil_div(npad * 8, 256)), dim3(256), 0, st, X, ldx, idx, n,
+                       npad, d, iw, muw, img, norms);
+}
+
 int launch_kmatmat_bf16x3(int kind, const float* X1, int64_t n1, int64_t ldx1, const int64_t* idx1,
                           const float* X2, int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d, float w,
                           const float* ell_vec, const float* center, float scale, const float* V, int k,

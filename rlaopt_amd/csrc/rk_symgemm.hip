@@ -47,6 +47,7 @@
 #include <stdlib.h>
 
 #include "rk_common.h"
+#include "rk_kerneltile.h"
 
 namespace rk {
 
@@ -426,6 +427,247 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same wide product with the K tile COMPUTED in the kernel (matrix-free operators: no n x n storage, no
+// temporary strips):   Y (n1 x r) = scale * K(X1, X2) V,   float32, d <= 64, kernels smooth in the squared distance.
+//
+// Structure of symgemm_kernel (128 rows x TN columns of Y per workgroup, contraction in steps of 32 points of X2,
+// V tiles from the pre-split image, two LDS buffers, one barrier per step, two-level accumulation) with the staging
+// of a K tile replaced by its evaluation, flash-style:
+//   * X1 and X2 are centred, scaled, split into two float16 pieces and written once per call as the 64-point images
+//     of rk_kernelbf16.hip (gram_split_kernel: |x'|^2 <= 32 is the caller's bound, the same guard as the matrix-free
+//     product);
+//   * per step a wave owns 16 rows i of the tile: S^T[j][i] = X2_tile X1_rows^T by 12 v_mfma_f32_16x16x32_f16 (two
+//     16-point blocks x two 32-feature steps x the three exact piece products; the X1 operand stays in 16 registers,
+//     the X2 tile comes from a three-slot LDS ring that is filled one step ahead), kappa(|x|^2 + |y|^2 - 2 S) on the
+//     accumulators - element v of a lane is (j = 4 (lane / 16) + v, i = lane % 16): four consecutive j of one row -
+//     then scale, split and ONE 8-byte LDS store per piece and block into the A-operand image the main product reads;
+//   * 12 + 48 matrix-core instructions per wave and step instead of 48, ~60 more vector instructions than the split of
+//     loaded entries.  Every workgroup evaluates its own tiles: with r = 512 (two column tiles) every entry is
+//     evaluated twice - still far cheaper than writing it (the strip-subset route: 80 ms of evaluation + five partial
+//     products with a tail each).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int KG_IMG = 16384, KG_SPLIT = 8192;  // one 64-point image: two pieces of 64 points x 64 features (float16)
+constexpr int KG_TILE = 2 * 4096;               // one 32-point tile of it: two pieces x 32 points x 128 B
+constexpr int KG_SLOT = KG_TILE + 128;          // + |y'|^2 of the 32 points
+constexpr float KG_UNSCALE = 1.f / 1048576.f;   // the pieces hold x' 2^10
+__host__ __device__ __forceinline__ int kg_chunk(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+void gram_prep_launch(const float* center, const float* ell_vec, int64_t d, float* iw, float* muw, hipStream_t st);
+void gram_split64_launch(const float* X, int64_t ldx, const int64_t* idx, int64_t n, int64_t npad, int64_t d,
+                         const float* iw, const float* muw, unsigned char* img, float* norms, hipStream_t st);
+
+template <int NCB, int KIND>
+__global__ void __launch_bounds__(SG_THREADS, 2)
+kgemm_kernel(const unsigned char* __restrict__ ximg1, const float* __restrict__ xn1, int64_t n1,
+             const unsigned char* __restrict__ ximg2, const float* __restrict__ xn2, int64_t n2, float w, float kscale,
+             float sa, const unsigned char* __restrict__ img, int64_t nct, const unsigned* __restrict__ info, int64_t k,
+             float* __restrict__ Y, int64_t ldy, int fold_mask) {
+    using F = SgF16;
+    constexpr int NS = 2;
+    constexpr int TN = 32 * NCB;
+    constexpr int ABYTES = SG_TM * SG_ROWB;
+    constexpr int BBYTES = TN * SG_ROWB;
+    constexpr int NBQ = NS * BBYTES / 16 / SG_THREADS;
+    constexpr bool RBF = KIND == RK_RBF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* AL = smem;                               // [2][NS][ABYTES]
+    unsigned char* BL = smem + 2 * NS * ABYTES;             // [2][NS][BBYTES]
+    unsigned char* XJ = BL + 2 * NS * BBYTES;               // [3][KG_SLOT]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t grp = (int64_t)blockIdx.x / (8 * nct);
+    const int64_t rem = (int64_t)blockIdx.x % (8 * nct);
+    const int64_t rb = grp * 8 + (rem & 7);  // (column tiles of a row block 8 ids apart: one XCD, they share the X2 / V tiles)
+    const int64_t ct = rem >> 3;
+    const int64_t i0 = rb * SG_TM;
+    if (i0 >= n1) return;  // (uniform, before any barrier)
+    const int64_t nst = (n2 + SG_KT - 1) / SG_KT;
+    const float rbf_c = -0.5f * w * w * 1.4426950408889634f;  // exp(-s w^2 / 2) = exp2(rbf_c s)
+    const float m2c = -2.f * rbf_c * KG_UNSCALE;
+    const float pscale = kscale * sa;  // (the image of K is scaled below 2^14 by sa = 2^ea, like the stored strips)
+
+    // this wave's 16 rows of X1 as B operand of S^T (2 feature steps x 2 pieces), and their |x'|^2
+    sg_u4 xi[2][2];
+    float ni;
+    {
+        const int64_t ip = i0 + 16 * wave + lr;  // < round_up(n1, 128): the image exists
+        const unsigned char* base = ximg1 + (ip >> 6) * KG_IMG;
+        const int r = (int)(ip & 63);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const unsigned char* src = base + kg_chunk(r, 4 * ks + lq);
+            xi[ks][0] = *reinterpret_cast<const sg_u4*>(src);
+            xi[ks][1] = *reinterpret_cast<const sg_u4*>(src + KG_SPLIT);
+        }
+        ni = xn1[ip] * (RBF ? rbf_c : 1.f);
+    }
+
+    sg_acc acc[SG_RB][NCB], tot[SG_RB][NCB];
+#pragma unroll
+    for (int r = 0; r < SG_RB; ++r)
+#pragma unroll
+        for (int c = 0; c < NCB; ++c)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { acc[r][c][v] = 0.f; tot[r][c][v] = 0.f; }
+    auto fold = [&]() {
+#pragma unroll
+        for (int r = 0; r < SG_RB; ++r)
+#pragma unroll
+            for (int c = 0; c < NCB; ++c) {
+                tot[r][c] += acc[r][c];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[r][c][v] = 0.f;
+            }
+    };
+
+    struct Stage {
+        sg_u4 b[NBQ];
+        sg_u4 xj;   // this thread's 16 bytes of the X2 tile of the step AFTER the stage's
+        float nj;   // |y'|^2 of point tid & 31 of that tile
+    };
+    Stage sA, sB;
+    auto clampq = [&](int64_t q) { return q < nst ? q : nst - 1; };
+    // X2 tile t: image t / 2, its points 32 (t % 2) .. + 32; piece tid / 256, 16-byte chunk tid % 256 of the piece's 4 KiB
+    auto load_xj = [&](int64_t t, sg_u4& xj, float& nj) {
+        t = clampq(t);
+        const unsigned char* src = ximg2 + (t >> 1) * KG_IMG + (tid >> 8) * KG_SPLIT + (int)(t & 1) * 4096 + (tid & 255) * 16;
+        xj = *reinterpret_cast<const sg_u4*>(src);
+        nj = xn2[t * SG_KT + (tid & 31)];
+    };
+    auto store_xj = [&](int64_t t, const sg_u4& xj, float nj) {
+        unsigned char* slot = XJ + (int)(t % 3) * KG_SLOT;
+        *reinterpret_cast<sg_u4*>(slot + (tid >> 8) * 4096 + (tid & 255) * 16) = xj;
+        if (tid < 32) reinterpret_cast<float*>(slot + KG_TILE)[tid] = nj;
+    };
+    auto load_c = [&](int64_t q, Stage& st) {
+        q = clampq(q);
+        const sg_u4* src = reinterpret_cast<const sg_u4*>(img + ((q * nct + ct) * NS) * (int64_t)BBYTES);
+#pragma unroll
+        for (int e = 0; e < NBQ; ++e) st.b[e] = src[tid + SG_THREADS * e];
+        load_xj(q + 1, st.xj, st.nj);
+    };
+    // stage step q: X2 tile q + 1 into the ring, the V tile into BL[buf], and the K tile of step q - evaluated from ring
+    // slot q % 3, which an earlier stage filled before the last barrier - into AL[buf]
+    auto store_c = [&](int buf, int64_t q, const Stage& st) {
+        store_xj(q + 1, st.xj, st.nj);
+        sg_u4* dstb = reinterpret_cast<sg_u4*>(BL + buf * NS * BBYTES);
+#pragma unroll
+        for (int e = 0; e < NBQ; ++e) dstb[tid + SG_THREADS * e] = st.b[e];
+        const unsigned char* slot = XJ + (int)(q % 3) * KG_SLOT;
+        unsigned char* al = AL + buf * NS * ABYTES;
+        const int row = 16 * wave + lr;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            sg_acc sj;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sj[v] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned char* src = slot + kg_chunk(16 * jb + lr, 4 * ks + lq);
+                const sg_u4 ah = *reinterpret_cast<const sg_u4*>(src);
+                const sg_u4 am = *reinterpret_cast<const sg_u4*>(src + 4096);
+                sj = F::mfma(am, xi[ks][0], sj);
+                sj = F::mfma(ah, xi[ks][1], sj);
+                sj = F::mfma(ah, xi[ks][0], sj);
+            }
+            const float4 nj4 = *reinterpret_cast<const float4*>(slot + KG_TILE + (16 * jb + 4 * lq) * 4);
+            const float njv[4] = {nj4.x, nj4.y, nj4.z, nj4.w};
+            float p[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                if constexpr (RBF) {
+                    p[v] = __builtin_amdgcn_exp2f(fmaf(sj[v], m2c, ni + njv[v] * rbf_c));
+                } else {
+                    float s = ni + njv[v] - (2.f * KG_UNSCALE) * sj[v];
+                    s = s > 0.f ? s : 0.f;
+                    p[v] = kernel_value<float>(KIND, s, w);
+                }
+                p[v] *= pscale;
+            }
+            unsigned pk[2][NS];
+            F::split2(p[0], p[1], pk[0]);
+            F::split2(p[2], p[3], pk[1]);
+            // columns j = 16 jb + 4 lq .. + 3 of tile row `row`: 16-byte chunk 2 jb + lq / 2, its half lq % 2
+            unsigned char* dst = al + row * SG_ROWB + (sg_swz(row, 2 * jb + (lq >> 1)) << 4) + (lq & 1) * 8;
+#pragma unroll
+            for (int pc = 0; pc < NS; ++pc) {
+                sg_u2 o;
+                o.x = pk[0][pc]; o.y = pk[1][pc];
+                *reinterpret_cast<sg_u2*>(dst + pc * ABYTES) = o;
+            }
+        }
+    };
+    const int a_off = (wr * 16 * SG_RB + lr) * SG_ROWB + (sg_swz(lr, lq) << 4);
+    const int b_off = (wc * (TN / 2) + lr) * SG_ROWB + (sg_swz(lr, lq) << 4);
+    auto compute = [&](int buf) {
+        const unsigned char* al = AL + buf * NS * ABYTES + a_off;
+        const unsigned char* bl = BL + buf * NS * BBYTES + b_off;
+        sg_u4 af[SG_RB][NS];
+#pragma unroll
+        for (int r = 0; r < SG_RB; ++r)
+#pragma unroll
+            for (int pc = 0; pc < NS; ++pc)
+                af[r][pc] = *reinterpret_cast<const sg_u4*>(al + r * 16 * SG_ROWB + pc * ABYTES);
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) {
+            sg_u4 bf[NS];
+#pragma unroll
+            for (int pc = 0; pc < NS; ++pc) bf[pc] = *reinterpret_cast<const sg_u4*>(bl + c * 16 * SG_ROWB + pc * BBYTES);
+#pragma unroll
+            for (int r = 0; r < SG_RB; ++r) {
+                acc[r][c] = F::mfma(af[r][1], bf[0], acc[r][c]);
+                acc[r][c] = F::mfma(af[r][0], bf[1], acc[r][c]);
+                acc[r][c] = F::mfma(af[r][0], bf[0], acc[r][c]);
+            }
+        }
+    };
+
+    // ---- pipeline (run_phase of symgemm_kernel with the step index passed to the staging) ------------------------------
+    {
+        sg_u4 x0;
+        float n0;
+        load_xj(0, x0, n0);
+        store_xj(0, x0, n0);
+    }
+    __syncthreads();  // ring slot 0 holds X2 tile 0
+    load_c(0, sA);
+    store_c(0, 0, sA);
+    load_c(1, sA);
+    load_c(2, sB);
+    __syncthreads();
+    for (int64_t q = 0; q < nst; q += 2) {
+        store_c(1, q + 1, sA);
+        load_c(q + 3, sA);
+        compute(0);
+        if (((int)q & fold_mask) == fold_mask) fold();
+        __syncthreads();
+        if (q + 1 < nst) {
+            store_c(0, q + 2, sB);
+            load_c(q + 4, sB);
+            compute(1);
+            if (((int)(q + 1) & fold_mask) == fold_mask) fold();
+            __syncthreads();
+        }
+    }
+    const int64_t kpad = nct * TN;
+    // (the unscaling alpha 2^-(ea + eb) rides in info[2 kpad + col])
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        const int64_t col = ct * TN + wc * (TN / 2) + c * 16 + lr;
+        const float unscale = __uint_as_float(info[2 * kpad + col]);
+#pragma unroll
+        for (int r = 0; r < SG_RB; ++r)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int64_t row = i0 + wr * 16 * SG_RB + r * 16 + 4 * lq + v;
+                if (row < n1 && col < k) Y[row * ldy + col] = (tot[r][c][v] + acc[r][c][v]) * unscale;
+            }
+    }
+}
+
 static bool sg_use_bf16x3() {
     const char* e = getenv("RK_SYMGEMM_SPLIT");
     return e != nullptr && (e[0] == 'b' || e[0] == '3');
@@ -528,4 +770,104 @@ extern "C" int rk_symm_gemm(const void* Kp, int64_t n, int64_t strip_first, int6
     }
 #undef RK_SG
     return launch_status("rk_symm_gemm");
+}
+
+// ---- the fused evaluate-and-multiply product (matrix-free operators) -------------------------------------------------
+static size_t kg_x_bytes(int64_t n) {  // |x'|^2 of the padded points + their split images
+    const int64_t npad = round_up(n, 256);
+    return (size_t)round_up(npad * (int64_t)sizeof(float), 256) + (size_t)(npad / 64) * KG_IMG;
+}
+
+extern "C" size_t rk_kernel_sketch_ws_bytes(int64_t n1, int64_t n2, int64_t k) {
+    if (n1 <= 0 || n2 <= 0 || k <= 0) return 0;
+    return SG_INFO_BYTES + sg_image_bytes(n2, k, 2) + 1024 + kg_x_bytes(n1) + kg_x_bytes(n2);
+}
+
+extern "C" int rk_kernel_sketch_matmat(int kind, const void* X1, int64_t n1, int64_t ldx1, const void* X2, int64_t n2,
+                                       int64_t ldx2, int64_t d, double ell_scalar, const void* ell_vec,
+                                       const void* center, double scale, const void* V, int64_t k, int64_t ldv,
+                                       double alpha, void* Y, int64_t ldy, void* ws, size_t ws_bytes, void* stream) {
+    clear_error();
+    RK_REQUIRE(X1 && X2 && V && Y && center, "rk_kernel_sketch_matmat: null pointer (the centre is required)");
+    RK_REQUIRE(kind == RK_RBF || kind == RK_MATERN32 || kind == RK_MATERN52,
+               "rk_kernel_sketch_matmat: kernels smooth in the squared distance only (rbf, matern32, matern52)");
+    RK_REQUIRE(d > 0 && d <= 64 && ldx1 >= d && ldx2 >= d, "rk_kernel_sketch_matmat: 1 <= d <= 64");
+    RK_REQUIRE(n1 > 0 && n2 > 0 && k > 0 && k <= 1024 && ldv >= k && ldy >= k,
+               "rk_kernel_sketch_matmat: bad sizes (n1=%lld n2=%lld k=%lld)", (long long)n1, (long long)n2, (long long)k);
+    RK_REQUIRE(ell_vec != nullptr || ell_scalar > 0.0, "rk_kernel_sketch_matmat: lengthscale must be positive");
+    RK_REQUIRE(scale != 0.0 && fabs(scale) < 1e30, "rk_kernel_sketch_matmat: scale must be finite and non-zero");
+    const size_t need = rk_kernel_sketch_ws_bytes(n1, n2, k);
+    if (ws == nullptr || ws_bytes < need || !aligned16(ws)) {
+        set_error("rk_kernel_sketch_matmat: workspace %zu B < required %zu B (16-byte aligned)", ws_bytes, need);
+        return RK_ERR_WORKSPACE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned char* base = static_cast<unsigned char*>(ws);
+    unsigned* info = reinterpret_cast<unsigned*>(base);
+    unsigned char* img = base + SG_INFO_BYTES;
+    float* iw = reinterpret_cast<float*>(img + sg_image_bytes(n2, k, 2));
+    float* muw = iw + 128;
+    const bool same = X1 == X2 && n1 == n2 && ldx1 == ldx2;
+    const int64_t n1pad = round_up(n1, 256), n2pad = round_up(n2, 256);
+    float* xn1 = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(iw) + 1024);
+    unsigned char* ximg1 = reinterpret_cast<unsigned char*>(xn1) + round_up(n1pad * (int64_t)sizeof(float), 256);
+    float* xn2 = same ? xn1 : reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(xn1) + kg_x_bytes(n1));
+    unsigned char* ximg2 = same ? ximg1 : reinterpret_cast<unsigned char*>(xn2) + round_up(n2pad * (int64_t)sizeof(float), 256);
+    gram_prep_launch((const float*)center, (const float*)ell_vec, d, iw, muw, st);
+    gram_split64_launch((const float*)X1, ldx1, nullptr, n1, n1pad, d, iw, muw, ximg1, xn1, st);
+    if (!same) gram_split64_launch((const float*)X2, ldx2, nullptr, n2, n2pad, d, iw, muw, ximg2, xn2, st);
+    // the split image of V and the column scales: as rk_symm_gemm (entries of K are bounded by |scale|)
+    const int tn = sg_tn(k);
+    const int64_t npadv = round_up(n2, SgLayout::W), kpad = round_up(k, tn), nct = kpad / tn;
+    int ex;
+    frexp(fabs(scale), &ex);
+    const int ea = 14 - ex;
+    if (hipMemsetAsync(info, 0, SG_INFO_BYTES, st) != hipSuccess) return launch_status("rk_kernel_sketch_matmat(memset)");
+    hipLaunchKernelGGL(sg_absmax_kernel, dim3((unsigned)ceil_div(k, 64), 512), dim3(256), 0, st, (const float*)V, n2, k,
+                       ldv, info);
+    hipLaunchKernelGGL(sg_scale_kernel, dim3((unsigned)ceil_div(kpad, 256)), dim3(256), 0, st, info, kpad, ea, (float)alpha, 1);
+    hipLaunchKernelGGL(sg_split_rhs_kernel<SgF16>, dim3((unsigned)ceil_div((npadv / 8) * kpad, 256)), dim3(256), 0, st,
+                       (const float*)V, n2, npadv, k, kpad, ldv, tn, info, img);
+    int rc = launch_status("rk_kernel_sketch_matmat(split)");
+    if (rc != RK_OK) return rc;
+    const int64_t nrb = ceil_div(n1, SG_TM);
+    const dim3 grid((unsigned)(ceil_div(nrb, 8) * 8 * nct));
+    const float w = ell_vec ? 1.f : (float)(1.0 / ell_scalar);
+    const float sa = (float)ldexp(1.0, ea);
+    int fold_steps = SG_FOLD;
+    if (const char* e = getenv("RK_SYMGEMM_FOLD")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 4096 && (v & (v - 1)) == 0) fold_steps = v;
+    }
+    const int fold_mask = fold_steps - 1;
+#define RK_KG(NCBV, KINDV)                                                                                          \
+    do {                                                                                                            \
+        constexpr size_t smem = 2 * 2 * (SG_TM * SG_ROWB + 32 * NCBV * SG_ROWB) + 3 * KG_SLOT;                      \
+        static std::atomic<unsigned long long> attr_devs{0};                                                        \
+        int dev_ = 0;                                                                                               \
+        (void)hipGetDevice(&dev_);                                                                                  \
+        const unsigned long long bit_ = 1ull << (dev_ & 63);                                                        \
+        if (!(attr_devs.load(std::memory_order_acquire) & bit_)) {                                                  \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kgemm_kernel<NCBV, KINDV>),                       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {         \
+                (void)hipGetLastError();                                                                            \
+                set_error("rk_kernel_sketch_matmat: cannot reserve %zu bytes of LDS", smem);                        \
+                return RK_ERR_LAUNCH;                                                                               \
+            }                                                                                                       \
+            attr_devs.fetch_or(bit_, std::memory_order_release);                                                    \
+        }                                                                                                           \
+        hipLaunchKernelGGL((kgemm_kernel<NCBV, KINDV>), grid, dim3(SG_THREADS), smem, st, ximg1, xn1, n1, ximg2, xn2, n2, \
+                           w, (float)scale, sa, img, nct, info, k, (float*)Y, ldy, fold_mask);                      \
+    } while (0)
+#define RK_KG_KIND(NCBV)                                                \
+    do {                                                                \
+        if (kind == RK_RBF) RK_KG(NCBV, RK_RBF);                        \
+        else if (kind == RK_MATERN32) RK_KG(NCBV, RK_MATERN32);         \
+        else RK_KG(NCBV, RK_MATERN52);                                  \
+    } while (0)
+    if (tn == 256) RK_KG_KIND(8);
+    else RK_KG_KIND(4);
+#undef RK_KG_KIND
+#undef RK_KG
+    return launch_status("rk_kernel_sketch_matmat");
 }

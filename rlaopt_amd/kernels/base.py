@@ -309,6 +309,15 @@ class _KernelBlock:
     def _matmat_wide(self, x):
         be = get_backend()
         m, n = self.A1.shape[0], self.A2.shape[0]
+        if (self.A1.dtype == torch.float32 and x.is_cuda and x.ndim == 2 and x.dtype in (torch.float32, torch.float64)
+                and self.A1.shape[1] <= 64 and self.kind in ("rbf", "matern32", "matern52") and self.scale != 0.0
+                and hasattr(be, "kernel_sketch_matmat") and self.gram_center is not None
+                and os.environ.get("RK_FREE_WIDE_FUSED", "1") != "0"):
+            # the kernel entries are evaluated inside the product (flash-style): no storage at all, rectangular
+            # shards included
+            xs = x if x.dtype == torch.float32 else x.float()
+            return be.kernel_sketch_matmat(self.kind, self.A1, self.A2, self.config.lengthscale, xs, scale=self.scale,
+                                           gram_center=self.gram_center, tag="kernel_sketch_product").to(x.dtype)
         if (self._symmetric and m == n and self.A1.dtype == torch.float32 and x.is_cuda and x.ndim == 2
                 and self.scale != 0.0 and hasattr(be, "symm_gemm") and hasattr(be, "sympack_elems")
                 and os.environ.get("RK_FREE_WIDE_STRIPS", "1") != "0"):

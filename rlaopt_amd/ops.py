@@ -384,6 +384,30 @@ class HipBackend:
         return out
 
     # -- dense products ----------------------------------------------------------------
+    def kernel_sketch_matmat(self, kind, X1, X2, lengthscale, V, scale=1.0, gram_center=None, alpha=1.0, tag=None):
+        """alpha * scale * K(X1, X2) @ V for MANY columns with the kernel entries evaluated inside the product
+        (``rk_kernel_sketch_matmat``: float32, d <= 64, rbf / matern32 / matern52, a ``gram_center`` from
+        :meth:`gram_center` required) - the sketch product of an operator that stores nothing."""
+        dev, kid, X1, ld1, X2, ld2, ell, ell_vec, _i1, _i2, n1, n2 = self._kernel_common(kind, X1, X2, lengthscale, None, None)
+        if gram_center is None or X1.dtype != torch.float32 or V.dtype != torch.float32 or V.ndim != 2 or V.shape[0] != n2:
+            raise ValueError("kernel_sketch_matmat: float32 data, a float32 n2 x k block and a gram_center")
+        _req(V, gram_center)
+        gram_center = gram_center.contiguous()
+        V2, ldv = _rowmajor(V)
+        k = V2.shape[1]
+        out = torch.empty((n1, k), dtype=torch.float32, device=dev)
+        for c0 in range(0, k, 1024):
+            kc = min(1024, k - c0)
+            nbytes = self._lib.rk_kernel_sketch_ws_bytes(n1, n2, kc)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)  # (its own buffer: hundreds of MB of split images)
+            with self._timed(tag or "rk_kernel_sketch_matmat", dev, 0):
+                rc = self._lib.rk_kernel_sketch_matmat(
+                    kid, _ptr(X1), n1, ld1, _ptr(X2), n2, ld2, X1.shape[1], ell, _ptr(ell_vec), _ptr(gram_center),
+                    float(scale), V2.data_ptr() + c0 * 4, kc, ldv, float(alpha), out.data_ptr() + c0 * 4, k, _ptr(ws),
+                    nbytes, _stream(dev))
+            _lib.check(rc, "rk_kernel_sketch_matmat")
+        return out
+
     def matmat(self, A, V, alpha=1.0, beta=0.0, C=None, diag_shift=0.0, row0=0, tag=None):
         """alpha * A @ V + beta * C + diag_shift * V[row0 : row0 + m].  ``tag`` names the
         launch in the optional timing table."""
@@ -770,7 +794,7 @@ def _guard_device(fn):
     return wrapped
 
 
-for _name in ("gram_center", "kernel_materialize", "kernel_matmat", "sympack_materialize", "symm_matmat",
+for _name in ("gram_center", "kernel_materialize", "kernel_matmat", "kernel_sketch_matmat", "sympack_materialize", "symm_matmat",
               "matmat", "rmatmat", "gemm", "gram_tn", "pcg_update_wr", "pcg_update_p", "axpby_cols",
               "normal_pass", "lsqr_tail", "small_solve", "sparse_sign_apply", "randn", "sample_distinct", "power_iteration",
               "sap_update"):

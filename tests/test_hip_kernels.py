@@ -641,8 +641,18 @@ def test_matrix_free_operator_wide_product_uses_panels(be, monkeypatch, prec):
         got = A @ M.to(dev())
         assert rel_err(got.cpu(), K @ M.double()) < LIM[dt] * 5, cols
     if dt == torch.float32:
-        # float32, symmetric data: the wide product above went through temporary cyclic strip subsets of the packed
-        # triangle + rk_symm_gemm (three subsets under this budget); the row-major panel route gives the same product
+        # float32, smooth kernel, d <= 64: the wide product above evaluated the entries INSIDE the product
+        # (rk_kernel_sketch_matmat).  Without it (RK_FREE_WIDE_FUSED=0), symmetric data go through temporary cyclic strip
+        # subsets of the packed triangle + rk_symm_gemm (two subsets under this budget); the row-major panel route
+        # gives the same product
+        fused_calls = []
+        real_f = be.kernel_sketch_matmat
+        monkeypatch.setattr(be, "kernel_sketch_matmat", lambda *a, **k: fused_calls.append(1) or real_f(*a, **k))
+        M = torch.randn(n, 130, dtype=dt, generator=gen)
+        got_f = A @ M.to(dev())
+        assert fused_calls == [1]
+        assert rel_err(got_f.cpu(), K @ M.double()) < LIM[dt] * 5
+        monkeypatch.setenv("RK_FREE_WIDE_FUSED", "0")
         calls = []
         real = be.symm_gemm
         monkeypatch.setattr(be, "symm_gemm", lambda *a, **k: calls.append(k.get("stride")) or real(*a, **k))
@@ -653,6 +663,38 @@ def test_matrix_free_operator_wide_product_uses_panels(be, monkeypatch, prec):
         panels = A @ M.to(dev())
         assert rel_err(got.cpu(), K @ M.double()) < LIM[dt] * 5
         assert rel_err(panels.cpu(), K @ M.double()) < LIM[dt] * 5
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern32", "matern52"])
+@pytest.mark.parametrize("n1,n2,d,k,ard", [(700, 700, 9, 130, False), (777, 1301, 33, 40, True), (1500, 515, 64, 300, False),
+                                           (129, 31, 5, 17, False), (2048, 2048, 64, 512, True)])
+def test_kernel_sketch_matmat_evaluates_inside_the_product(be, kind, n1, n2, d, k, ard):
+    """rk_kernel_sketch_matmat: alpha * scale * K(X1, X2) @ V with the entries evaluated tile by tile inside the wide
+    product (X2 tile x X1 rows on the 16-bit matrix cores, the kernel function on the accumulators, split, straight
+    into the operand image) - against the float64 oracle: square and rectangular point sets, sizes that are not
+    multiples of the 32-point steps or the 128-row blocks, scalar and per-feature lengthscales, un-centred data, one
+    and two column tiles, columns of very different magnitude, bitwise reproducibility."""
+    dt = torch.float32
+    g = torch.Generator().manual_seed(n1 + 7 * n2 + d)
+    X1 = torch.randn(n1, d, dtype=dt, generator=g) / d**0.5 + 3.0   # (a common offset: the centre removes it)
+    X2 = X1 if n1 == n2 else torch.randn(n2, d, dtype=dt, generator=g) / d**0.5 + 3.0
+    ell = (0.8 + 0.4 * torch.rand(d, dtype=dt, generator=g)) if ard else 1.1
+    V = torch.randn(n2, k, dtype=dt, generator=g) * torch.logspace(-4, 3, k, dtype=dt)
+    X1d = X1.to(dev())
+    X2d = X1d if n1 == n2 else X2.to(dev())
+    elld = ell.to(dev()) if ard else ell
+    gc = be.gram_center(X1d, X2d, elld)
+    assert gc is not None
+    want = -0.5 * (ok.kernel_matrix(kind, X1.double(), X2.double(), ell.double() if ard else ell, 0.7) @ V.double())
+    got = be.kernel_sketch_matmat(kind, X1d, X2d, elld, V.to(dev()), scale=0.7, gram_center=gc, alpha=-0.5)
+    again = be.kernel_sketch_matmat(kind, X1d, X2d, elld, V.to(dev()), scale=0.7, gram_center=gc, alpha=-0.5)
+    assert torch.equal(got, again)
+    err = (got.cpu().double() - want).norm(dim=0) / want.norm(dim=0)
+    assert float(err.max()) < 1e-5, (float(err.max()), int(err.argmax()))
+    with pytest.raises(ValueError):
+        be.kernel_sketch_matmat("laplace", X1d, X2d, elld, V.to(dev()), gram_center=gc)
+    with pytest.raises(ValueError):
+        be.kernel_sketch_matmat(kind, X1d, X2d, elld, V.to(dev()), gram_center=None)
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 16, 17, 1000, 4097, 500_000])

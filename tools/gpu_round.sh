@@ -30,6 +30,9 @@ timeout -k 10 500 python3 bench.py --dtype f64 --steps 20 --warmup 5 --no-cpu-ba
 timeout -k 10 400 python3 bench.py --dtype f64 --storage f32 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_f64_f32storage.log 2>/dev/null && echo "f64/f32 ok"
 # the multi-rank entry as the driver would call it: bench.py starts its own ranks (two gloo ranks on this one GPU)
 RK_BENCH_BACKEND=gloo RK_BENCH_ONE_GPU=1 timeout -k 10 500 python3 bench.py --gpus 2 --steps 20 --warmup 5 > $OUT/${TAG}_bench_gloo_world2_selflaunch.log 2>$OUT/${TAG}_bench_gloo_world2_selflaunch.err && echo "self-launched world 2 ok"
+# the sketch product of a matrix-free operator: entries evaluated inside the product; its matrix-core busy counter
+timeout -k 10 300 python3 tools/bench_ksketch.py > $OUT/${TAG}_bench_ksketch.log 2>&1 && echo "ksketch ok"
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/${TAG}_pmc_ksketch -o ${TAG} -- python3 tools/bench_ksketch.py --r 512 --reps 1 --only-fused --check-rows 0 > $OUT/${TAG}_pmc_ksketch.log 2>&1 && echo "pmc ksketch ok"
 timeout -k 10 200 python3 tools/profile_colsample.py > $OUT/${TAG}_profile_colsample.log 2>&1 && echo "colsample profile ok"
 timeout -k 10 200 python3 tools/profile_colsample.py --sketch gauss > $OUT/${TAG}_profile_gauss.log 2>&1 && echo "gauss profile ok"
 if [ "$PART" = "c" ]; then exit 0; fi

@@ -196,6 +196,7 @@ with open(f"{dst}/{tag}_summary.md", "w") as f:
                         ("bench_gloo_world2_selflaunch", "`RK_BENCH_BACKEND=gloo RK_BENCH_ONE_GPU=1 python3 bench.py --gpus 2`: bench.py starts its own ranks"),
                         ("symm_pmc_table", "Packed symmetric product (block kernel + finishing kernel): HBM traffic and matrix-core busy per k (tools/pmc_symm.sh)"),
                         ("wr_probe", "What stores cost beside a streaming read (tools/wr_probe.hip)"),
+                        ("bench_ksketch", "Sketch product of a matrix-free operator: entries evaluated inside the product (tools/bench_ksketch.py)"),
                         ("bench_f64", "Secondary line: bench.py --dtype f64 (float64 storage, 160 GB packed)"),
                         ("bench_f64_f32storage", "Secondary line: bench.py --dtype f64 --storage f32 (float64 iteration over the float32 triangle)"),
                         ("profile_colsample", "Nystrom assembly with the column-sampling sketch by stage (tools/profile_colsample.py)"),
@@ -212,6 +213,18 @@ with open(f"{dst}/{tag}_summary.md", "w") as f:
                 continue
             f.write(l[:600].rstrip() + "\n")
         f.write("```\n\n")
+    kf = f"{src}/{tag}_pmc_ksketch/{tag}_counter_collection.csv"
+    if os.path.exists(kf):
+        c = {}
+        for r in csv.DictReader(open(kf)):
+            if "kgemm_kernel" in r["Kernel_Name"]:
+                c.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("GRBM_GUI_ACTIVE"):
+            busy = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(c["SQ_VALU_MFMA_BUSY_CYCLES"])
+            gui = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"])
+            f.write(f"## Matrix cores of `kgemm_kernel` (rk_kernel_sketch_matmat, n = 200 000, r = 512; own PMC pass)\n\n"
+                    f"SQ_VALU_MFMA_BUSY_CYCLES = {busy:.4g} per launch, GRBM_GUI_ACTIVE = {gui:.4g} (8 XCDs) -> **matrix cores busy "
+                    f"{100 * busy / (gui / 8.0 * 1024.0):.1f} %** over {len(c['GRBM_GUI_ACTIVE'])} launch(es).\n\n")
     for name in ("smoke", "pytest_gpu"):
         blog = f"{src}/{tag}_{name}.log"
         if os.path.exists(blog):
