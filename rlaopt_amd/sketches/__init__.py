@@ -305,6 +305,8 @@ class ColSample(Sketch):
         lo <= J[p] < hi, else 0): the r x r Nystrom core, float64; per-rank partials add up."""
         J = self.indices.to(Y.device)
         hi = lo + Y.shape[0] if hi is None else hi
+        if Y.shape[0] == 0:  # (a rank that owns no rows still takes part in the all-reduce of the core)
+            return torch.zeros((J.numel(), Y.shape[1]), dtype=torch.float64, device=Y.device)
         inside = (J >= lo) & (J < hi)
         rows = Y[(J - lo).clamp(0, max(Y.shape[0] - 1, 0))].double() * self.col_scale
         return rows * inside[:, None].to(rows.dtype)

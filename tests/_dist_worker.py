@@ -62,6 +62,12 @@ def main():
             W, log = LinSys(sq, B, reg=0.5).solve(PCGConfig(device=cpu, max_iters=20, rtol=1e-12), torch.zeros(n, 1, dtype=dt), callback_freq=1)
             want = torch.linalg.solve(Ksq + 0.5 * torch.eye(n, dtype=dt), B)
             torch.testing.assert_close(W, want, rtol=1e-8, atol=1e-10)
+            # the column-sampling Nystrom preconditioner on the same layout (a rank without rows contributes zeros)
+            Wc, _ = LinSys(sq, B, reg=0.5).solve(
+                PCGConfig(device=cpu, max_iters=20, rtol=1e-12,
+                          precond_config=NystromConfig(rank=2, rho=0.5, sketch="colsample")),
+                torch.zeros(n, 1, dtype=dt), callback_freq=1)
+            torch.testing.assert_close(Wc, want, rtol=1e-8, atol=1e-10)
         td.barrier()
         if rank == 0:
             print(f"DIST-OK world={size} n={n} (fewer blocks than ranks)")

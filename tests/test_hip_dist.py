@@ -85,3 +85,42 @@ def test_rk_comm_transport_single_rank():
     with pytest.raises(ValueError):
         _lib.check(lib.rk_comm_allreduce_sum(comm, x.data_ptr(), 4, 7, st), "allreduce")
     _lib.check(lib.rk_comm_destroy(comm), "rk_comm_destroy")
+
+
+@pytest.mark.parametrize("devices,backend", [(1, "nccl"), (2, "gloo")])
+def test_one_process_multi_device_solve_runs_in_worker_processes(devices, backend, monkeypatch):
+    """rlaopt_amd/spmd.py on the GPU box: the whole solve of an operator flagged 'several devices in one process' is
+    executed by fresh worker processes - one RCCL rank on cuda:0 (RK_FORCE_SPMD: the collective code path with a world
+    of one), then two gloo ranks sharing cuda:0 - with the real HIP kernels (strip-packed SPMD storage); rank 0's
+    result equals the in-process solve."""
+    import torch
+
+    from rlaopt_amd import sketches, spmd
+    from rlaopt_amd.kernels import DistributedRBFLinOp, KernelConfig
+    from rlaopt_amd.models import LinSys
+    from rlaopt_amd.preconditioners import NystromConfig
+    from rlaopt_amd.solvers import PCGConfig
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    n, d, k = 2500, 8, 2
+    dt = torch.float64
+    X = (torch.randn(n, d, dtype=dt, generator=g) / d**0.5).to(dev)
+    B = torch.randn(n, k, dtype=dt, generator=g).to(dev)
+    reg = 1e-3 * n
+    cfg = PCGConfig(device=dev, max_iters=100, atol=0.0, rtol=1e-9, precond_config=NystromConfig(rank=32, rho=reg))
+    A = DistributedRBFLinOp(X, X, KernelConfig(lengthscale=1.0), devices={dev})
+    W_ref, log_ref = LinSys(A, B, reg=reg).solve(cfg, torch.zeros_like(B), callback_freq=5)
+    A._inprocess_multi_device = True
+    A._shard_devices = [dev] * devices
+    if devices == 1:
+        monkeypatch.setenv("RK_FORCE_SPMD", "1")
+    real = spmd.solve_kernel_system
+    monkeypatch.setattr(spmd, "solve_kernel_system", lambda *a, **kw: real(*a, backend=backend, timeout=300, **kw))
+    W, log = LinSys(A, B, reg=reg).solve(cfg, torch.zeros_like(B), callback_freq=5)
+    assert W.device == B.device
+    assert max(log) <= max(log_ref) + 5
+    K = A @ torch.eye(n, dtype=dt, device=dev)
+    res = torch.linalg.norm(B - (K @ W + reg * W), dim=0) / torch.linalg.norm(B, dim=0)
+    assert bool((res <= 1e-9).all()), res
+    assert float((W - W_ref).norm() / W_ref.norm()) < 1e-6
