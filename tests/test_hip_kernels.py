@@ -954,7 +954,8 @@ def test_integration_md_stub_runs_against_the_oracle(be, prec, name, kind):
 @pytest.mark.parametrize("n,k,first,stride", [(300, 5, 0, 1), (1000, 16, 0, 1), (2304, 7, 0, 1), (3000, 10, 0, 1),
                                              (5000, 16, 0, 1), (4100, 9, 1, 3), (2600, 12, 0, 2), (1500, 1, 0, 1),
                                              (33, 6, 0, 1), (1025, 4, 0, 1), (2049, 3, 0, 1), (6200, 11, 0, 1),
-                                             (9000, 16, 2, 5), (7000, 8, 0, 8)])
+                                             (9000, 16, 2, 5), (7000, 8, 0, 8), (1, 1, 0, 1), (31, 3, 0, 1), (257, 2, 0, 1),
+                                             (1024, 16, 0, 1), (1280, 1, 1, 2), (4097, 4, 3, 4)])
 def test_symm_matmat_f16x2_matrix_core_strip_product(be, n, k, first, stride):
     """rk_symm_matmat_f16x2: the packed symmetric product for up to 16 right-hand sides on the 16-bit matrix
     cores (two float16 pieces per factor, row reads and transposing reads of one LDS image) against the float64
