@@ -110,3 +110,43 @@ def test_streaming_products_many_columns_random_shapes(be, monkeypatch, seed):
     got = be.matmat(Afull.to(DEV)[:, :nn], W.to(DEV), diag_shift=0.25 if m <= nn else 0.0)
     want = Afull[:, :nn] @ W + (0.25 * W[:m] if m <= nn else 0.0)
     assert rel_err(got, want) < 1e-13, (m, nn, kk, pad)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_block_symmetric_product_and_fused_sketch_random_shapes(be, monkeypatch, seed):
+    """Round 4: the block form of the packed symmetric product (any width 1 .. 16, any cyclic strip distribution: the
+    ranks' partials add up) and the sketch product with the entries evaluated inside it (rectangular point sets, any
+    width up to 600), at sizes around the 256-column strips, the 1024-column groups, the 32-row tiles, the 128-row
+    blocks - each against the float64 oracle."""
+    rng = random.Random(4000 + seed)
+    gen = torch.Generator().manual_seed(seed)
+    monkeypatch.setenv("RK_SYMM_F16X2_MIN_BYTES", "0")
+    n = _near(rng, [1, 33, 256, 257, 1024, 1025, 2048, 3100, 5121], 2)
+    d = rng.choice([3, 16, 40, 64])
+    k = rng.choice([1, 2, 3, 5, 8, 11, 16])
+    stride = rng.choice([1, 1, 2, 3, 5])
+    kind = rng.choice(["rbf", "matern32", "matern52"])
+    scale = rng.choice([1.0, 0.3, 4.0])
+    X = torch.randn(n, d, generator=gen) / d**0.5
+    V = torch.randn(n, k, generator=gen) * torch.logspace(-3, 2, k)
+    Xd, Vd = X.to(DEV), V.to(DEV)
+    Kd = ok.kernel_matrix(kind, X.double(), X.double(), 1.1, scale)
+    want = Kd @ V.double() + 0.5 * V.double()
+    total = torch.zeros(n, k, dtype=torch.float64)
+    for f in range(stride):
+        Kp = be.sympack_materialize(kind, Xd, 1.1, scale=scale, first=f, stride=stride)
+        total += be.symm_matmat(Kp, n, Vd, diag_shift=0.5 if f == 0 else 0.0, first=f, stride=stride,
+                                kmax=scale).cpu().double()
+    err = (total - want).norm(dim=0) / want.norm(dim=0)
+    assert float(err.max()) < 5e-6, (n, d, k, stride, kind, float(err.max()))
+    # the fused sketch product on the same points against a second, rectangular set
+    n2 = _near(rng, [31, 129, 700, 1500], 3)
+    r = rng.choice([17, 64, 130, 257, 600])
+    X2 = torch.randn(n2, d, generator=gen) / d**0.5
+    Om = torch.randn(n2, r, generator=gen)
+    X2d = X2.to(DEV)
+    gc = be.gram_center(Xd, X2d, 1.1)
+    assert gc is not None
+    got = be.kernel_sketch_matmat(kind, Xd, X2d, 1.1, Om.to(DEV), scale=scale, gram_center=gc)
+    want2 = ok.kernel_matrix(kind, X.double(), X2.double(), 1.1, scale) @ Om.double()
+    assert rel_err(got, want2) < 1e-5, (n, n2, d, r, kind)
