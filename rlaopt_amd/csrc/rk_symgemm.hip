@@ -67,6 +67,17 @@ struct SgLayout {  // the packed layout of rk_symm.hip for float32 storage (W = 
 typedef unsigned int sg_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned int sg_u2 __attribute__((ext_vector_type(2)));
 typedef float sg_acc __attribute__((ext_vector_type(4)));
+typedef float sg_acc16 __attribute__((ext_vector_type(16)));
+// RK_SG_M32 = 1: the main product on v_mfma_f32_32x32x16_* (a wave's 32 x 128 part of Y = 4 blocks of 32 x 32) instead of
+// 16x16x32 (2 x 8 blocks of 16 x 16): the same matrix-core cycles and LDS reads, HALF the matrix-core instructions - each
+// holds the SIMD's vector issue port for 8 cycles, and with two waves per SIMD the port (matrix-core issue + ~100 vector +
+// ~26 LDS instructions per wave and step) looked like what the step waits for (SQ_WAIT_INST_ANY 40 % of wave cycles).
+// Measured (profiles/r04_symgemm_m32.log): SLOWER - 131.7 against 122.1 ms (three bfloat16 pieces: 242 against 207 ms),
+// same results: the port is not the bound (and the 32 x 32 form holds a lower clock under load: MI355X_MICROARCH.md,
+// DVFS item 7).  Kept as a build option.
+#ifndef RK_SG_M32
+#define RK_SG_M32 0
+#endif
 typedef _Float16 sg_h8 __attribute__((ext_vector_type(8)));
 typedef __bf16 sg_b8 __attribute__((ext_vector_type(8)));
 
@@ -98,6 +109,9 @@ struct SgF16 {  // two float16 pieces, three products
     __device__ static __forceinline__ sg_acc mfma(sg_u4 a, sg_u4 b, sg_acc c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sg_h8, a), __builtin_bit_cast(sg_h8, b), c, 0, 0, 0);
     }
+    __device__ static __forceinline__ sg_acc16 mfma32(sg_u4 a, sg_u4 b, sg_acc16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sg_h8, a), __builtin_bit_cast(sg_h8, b), c, 0, 0, 0);
+    }
 };
 struct SgBf16 {  // three bfloat16 pieces, six products
     static constexpr int NS = 3;
@@ -123,6 +137,9 @@ struct SgBf16 {  // three bfloat16 pieces, six products
     }
     __device__ static __forceinline__ sg_acc mfma(sg_u4 a, sg_u4 b, sg_acc c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sg_b8, a), __builtin_bit_cast(sg_b8, b), c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ sg_acc16 mfma32(sg_u4 a, sg_u4 b, sg_acc16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sg_b8, a), __builtin_bit_cast(sg_b8, b), c, 0, 0, 0);
     }
 };
 
@@ -247,6 +264,22 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
     const int64_t nT = own ? b * (W / SG_KT) : 0;
     const int64_t nD = t_min < T ? (T - t_min) * (W / SG_KT) : 0;
 
+#if RK_SG_M32
+    constexpr int NC32 = NCB / 2;  // 32 x 32 blocks of this wave's 32 rows x TN / 2 columns
+    sg_acc16 acc[NC32], tot[NC32];
+#pragma unroll
+    for (int c = 0; c < NC32; ++c)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { acc[c][v] = 0.f; tot[c][v] = 0.f; }
+    auto fold = [&]() {
+#pragma unroll
+        for (int c = 0; c < NC32; ++c) {
+            tot[c] += acc[c];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[c][v] = 0.f;
+        }
+    };
+#else
     sg_acc acc[SG_RB][NCB];
 #pragma unroll
     for (int r = 0; r < SG_RB; ++r)
@@ -275,6 +308,7 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
                 for (int v = 0; v < 4; ++v) acc[r][c][v] = 0.f;
             }
     };
+#endif
 
     // two register sets: the loads of steps q + 2 and q + 3 are in flight while step q is computed (with one set -
     // one step of cover - a rank's partial over cyclically dealt strips, where both operands come from HBM, ran at
@@ -358,6 +392,36 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
         store_b(buf, st);
     };
     // ---- one step of matrix-core work out of LDS ----------------------------------------------------------
+#if RK_SG_M32
+    // operands of v_mfma_f32_32x32x16: lane (row or column lane % 32, 8 contraction indices 16 kk + 8 (lane / 32) .. + 8)
+    const int l32 = lane & 31, lh = lane >> 5;
+    const int a_off = (wr * 32 + l32) * SG_ROWB;
+    const int b_off = (wc * (TN / 2) + l32) * SG_ROWB;
+    auto compute = [&](int buf) {
+        const unsigned char* al = AL + buf * NS * ABYTES + a_off;
+        const unsigned char* bl = BL + buf * NS * BBYTES + b_off;
+        sg_u4 af[2][NS];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int p = 0; p < NS; ++p)
+                af[kk][p] = *reinterpret_cast<const sg_u4*>(al + (sg_swz(l32, 2 * kk + lh) << 4) + p * ABYTES);
+#pragma unroll
+        for (int c = 0; c < NC32; ++c) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                sg_u4 bf[NS];
+#pragma unroll
+                for (int p = 0; p < NS; ++p)
+                    bf[p] = *reinterpret_cast<const sg_u4*>(bl + c * 32 * SG_ROWB + (sg_swz(l32, 2 * kk + lh) << 4) + p * BBYTES);
+#pragma unroll
+                for (int sum = NS - 1; sum >= 0; --sum)
+#pragma unroll
+                    for (int pa = 0; pa <= sum; ++pa) acc[c] = F::mfma32(af[kk][pa], bf[sum - pa], acc[c]);
+            }
+        }
+    };
+#else
     const int a_off = (wr * 16 * SG_RB + lr) * SG_ROWB + (sg_swz(lr, lq) << 4);       // + rbk * 16 rows
     const int b_off = (wc * (TN / 2) + lr) * SG_ROWB + (sg_swz(lr, lq) << 4);         // + cb * 16 columns
     auto compute = [&](int buf) {
@@ -384,6 +448,7 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
             }
         }
     };
+#endif
 
     // ---- the two phases: transposed tiles, then direct tiles (same pipeline, different loads / stores) ----------
     auto run_phase = [&](auto load, auto store, int64_t nst) {
@@ -413,6 +478,21 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
     run_phase(load_d, store_d, nD);
     // ---- epilogue: element v of a lane is Y[row 4 (lane / 16) + v][column lane % 16] of its block -----------
     const int64_t kpad = nct * TN;
+#if RK_SG_M32
+    // element v of a 32 x 32 block: row (v & 3) + 8 (v >> 2) + 4 (lane / 32), column lane % 32
+#pragma unroll
+    for (int c = 0; c < NC32; ++c) {
+        const int64_t col = ct * TN + wc * (TN / 2) + c * 32 + l32;
+        const float unscale = __uint_as_float(info[2 * kpad + col]);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int64_t row = i0 + wr * 32 + (v & 3) + 8 * (v >> 2) + 4 * lh;
+            if (row < L.n && col < k) Y[row * ldy + col] = (tot[c][v] + acc[c][v]) * unscale;
+        }
+    }
+}
+
+#else
 #pragma unroll
     for (int c = 0; c < NCB; ++c) {
         const int64_t col = ct * TN + wc * (TN / 2) + c * 16 + lr;
@@ -426,6 +506,7 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
             }
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 // The same wide product with the K tile COMPUTED in the kernel (matrix-free operators: no n x n storage, no
