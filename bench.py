@@ -424,11 +424,8 @@ def main():
 
     mode = A.storage_mode
     # which kernel the timed products ran (decided here: the operator is released before the line is printed)
-    blk_kernel = bool(args.dtype == "f32" and getattr(A, "_sym", None) is not None
-                      and A._sym.store_dtype == torch.float32
-                      and A._sym.Kp.numel() * 4 >= float(os.environ.get("RK_SYMM_F16X2_MIN_BYTES", "24e9"))
-                      and os.environ.get("RK_SYMM_F16X2", "1") != "0"
-                      and int(os.environ.get("RK_SYMM_F16X2_MIN", "1")) <= 1)
+    blk_kernel = bool(getattr(A, "_sym", None) is not None and A._sym.store_dtype == torch.float32
+                      and os.environ.get("RK_SYMM_BLKREG", "1") != "0")
     mv = timing.get("kernel_shard_product", {"avg_ms": float("nan"), "bytes_per_launch": 0, "launches": 0})
     achieved = mv["bytes_per_launch"] / (mv["avg_ms"] * 1e-3) / 1e9 if mv["launches"] else float("nan")
     if world > 1:  # roofline is per GPU: report the slowest rank's kernel
@@ -573,9 +570,10 @@ def main():
                 "parallelism": f"row-shard x{world}",
             },
             "roofline": {
-                "kernel": (("rk_symm_matmat_f16x2 (symm_blk_h2_kernel + finish): strip-packed upper triangle, every stored "
-                            "entry used for y[i] and y[j], four strips side by side per work item, both uses on the 16-bit "
-                            "matrix cores with two float16 pieces per factor (float32 accuracy); "
+                "kernel": (("rk_symm_matmat (symm_blk_reg_kernel + finish): strip-packed upper triangle, every stored entry "
+                            "used for y[i] and y[j]; work items of four strips side by side x up to 1024 rows claimed from a "
+                            "device counter, a row's partial sum carried across the strips (vector units, exact "
+                            + ("float32" if args.dtype == "f32" else "float64 over float32 storage") + " arithmetic); "
                             if blk_kernel else
                             "rk_symm_matmat (symm_strip_kernel + finish): strip-packed upper triangle, every stored entry "
                             "used for y[i] and y[j]; ") + "algorithmic bytes = packed triangle + V + Y"

@@ -1086,6 +1086,11 @@ static bool symm_use_wide(int dtype, int store_dtype, int64_t k) {
     return !(e != nullptr && e[0] == '0');
 }
 
+static bool symm_use_blkreg() {
+    const char* e = getenv("RK_SYMM_BLKREG");
+    return !(e != nullptr && e[0] == '0');
+}
+
 static int check_layout(const char* fn, int dtype, int store_dtype, int64_t n, int64_t first,
                         int64_t stride) {
     RK_REQUIRE(dtype == RK_F32 || dtype == RK_F64, "%s: bad dtype %d", fn, dtype);
@@ -1140,8 +1145,12 @@ extern "C" size_t rk_symm_matmat_ws_bytes(int dtype, int store_dtype, int64_t n,
                                : symm_wide_ws_bytes<double>(n, strip_first, strip_stride);
     }
     if (k > 4) return 0;
-    if (dtype == RK_F32) return symm_ws_bytes<float, float>(n, k, strip_first, strip_stride);
-    return store_dtype == RK_F32 ? symm_ws_bytes<float, double>(n, k, strip_first, strip_stride)
+    auto both = [](size_t a, size_t b) { return a > b ? a : b; };  // (either implementation can run in it)
+    if (dtype == RK_F32)
+        return both(symm_ws_bytes<float, float>(n, k, strip_first, strip_stride),
+                    symm_blkreg_ws_bytes<float>(n, k, strip_first, strip_stride));
+    return store_dtype == RK_F32 ? both(symm_ws_bytes<float, double>(n, k, strip_first, strip_stride),
+                                        symm_blkreg_ws_bytes<double>(n, k, strip_first, strip_stride))
                                  : symm_ws_bytes<double, double>(n, k, strip_first, strip_stride);
 }
 
@@ -1166,6 +1175,17 @@ extern "C" int rk_symm_matmat(int dtype, int store_dtype, const void* Kp, int64_
                                                 ldv, alpha, diag_shift, (float*)Y, ldy, ws, ws_bytes, st);
         return symm_matmat_wide_impl<double>((const double*)Kp, n, strip_first, strip_stride, (const double*)V, k,
                                              ldv, alpha, diag_shift, (double*)Y, ldy, ws, ws_bytes, st);
+    }
+    // float32 storage, at most 4 columns: the block decomposition on the vector units (rk_symmblk.hip; RK_SYMM_BLKREG=0:
+    // the strip kernel)
+    // (one or two float32 columns, one float64 column: beyond that the per-lane column sums of four strips do not fit
+    // the registers at a useful occupancy)
+    if (store_dtype == RK_F32 && symm_use_blkreg() && k <= (dtype == RK_F32 ? 2 : 1)) {
+        if (dtype == RK_F32)
+            return symm_matmat_blkreg_impl<float>((const float*)Kp, n, strip_first, strip_stride, (const float*)V, k, ldv,
+                                                  alpha, diag_shift, (float*)Y, ldy, ws, ws_bytes, st);
+        return symm_matmat_blkreg_impl<double>((const float*)Kp, n, strip_first, strip_stride, (const double*)V, k, ldv,
+                                               alpha, diag_shift, (double*)Y, ldy, ws, ws_bytes, st);
     }
     if (dtype == RK_F32)
         return symm_matmat_impl<float, float>((const float*)Kp, n, strip_first, strip_stride,

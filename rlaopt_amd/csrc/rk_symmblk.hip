@@ -98,14 +98,14 @@ static int64_t blk_items(const BlkLayout& B) {
 // [256, 2048] that minimises rounds x (H + 40) among those that leave every CU at least 12 items (items are claimed
 // dynamically, so rounds are approximate: the tail is at most one item long).  n = 200 000 on one GPU (256 CUs): see
 // profiles/r04_ab_symm.log.  The choice is cached per (n, first, stride, CUs).
-static int pick_item_rows(BlkLayout B, int64_t cus) {
+static int pick_item_rows(BlkLayout B, int64_t cus, int hmax) {
     struct Key { int64_t n, first, stride, cus; int h; };
     static thread_local Key cache[8] = {};
     for (const Key& c : cache)
-        if (c.h && c.n == B.L.n && c.first == B.L.first && c.stride == B.L.stride && c.cus == cus) return c.h;
+        if (c.h && c.n == B.L.n && c.first == B.L.first && c.stride == B.L.stride && c.cus == cus + 100000 * (int64_t)hmax) return c.h;
     double best = 1e300;
     int best_h = 256;
-    for (int h = 2048; h >= 256; h -= 32) {
+    for (int h = hmax; h >= 256; h -= 32) {
         B.H = h;
         const int64_t items = blk_items(B);
         if (items < 12 * cus && h > 256) continue;
@@ -113,19 +113,19 @@ static int pick_item_rows(BlkLayout B, int64_t cus) {
         if (cost < best) { best = cost; best_h = h; }
     }
     static thread_local int next = 0;
-    cache[next] = Key{B.L.n, B.L.first, B.L.stride, cus, best_h};
+    cache[next] = Key{B.L.n, B.L.first, B.L.stride, cus + 100000 * (int64_t)hmax, best_h};
     next = (next + 1) % 8;
     return best_h;
 }
 
-static BlkLayout make_blk_layout(int64_t n, int64_t first, int64_t stride, int64_t cus = 256) {
+static BlkLayout make_blk_layout(int64_t n, int64_t first, int64_t stride, int64_t cus = 256, int hmax = 2048) {
     BlkLayout B;
     B.L = make_layout<float>(n, first, stride);
     B.T_loc = B.L.strips_local();
     B.Q = ceil_div(B.T_loc, B2_G);
     B.H = B2_H_FIXED;
     B.max_chunks = 0;
-    if (B2_H_FIXED == 0) B.H = B.Q > 0 ? pick_item_rows(B, cus) : 256;
+    if (B2_H_FIXED == 0 || hmax != 2048) B.H = B.Q > 0 ? pick_item_rows(B, cus, hmax) : 256;
     B.max_chunks = ceil_div(n, B.H);
     return B;
 }
@@ -416,6 +416,224 @@ symm_blk_finish_kernel(BlkLayout B, int K, const float* __restrict__ Prow, const
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same block decomposition on the VECTOR units, for what the 16-bit matrix cores cannot do: float64 vectors over the
+// float32 triangle (the converging configuration of the KRR solve) and float32 products of 1 .. 4 columns over shards
+// too small to amortise the split prologue.  A wave owns batches of RB rows of the item; per row it loads the SAME row of
+// the group's four strips (4 x 1 KiB, non-temporal), forms the row's partial dot products over all 1024 columns in its
+// lanes and reduces them ONCE (symm_strip_kernel reduces once per strip and writes a table row per strip: here the
+// (group, row) table is a quarter of that), and adds the column sums of the four strips in registers for the whole
+// item.  Items, tickets, tables and the finishing kernel are the block kernel's.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int BR_RB = 2;        // rows per batch: 8 loads of 1 KiB per stage, two stages per wave
+constexpr int BR_HMAX = 1024;   // rows per item at most (the row sums of an item wait in LDS)
+constexpr int BR_THREADS = 256;
+
+template <typename T, int K>
+__global__ void __launch_bounds__(BR_THREADS)
+symm_blk_reg_kernel(const float* __restrict__ Kp, BlkLayout B, const T* __restrict__ V, int64_t ldv,
+                    T* __restrict__ Prow, T* __restrict__ Pcol, int64_t total_items, unsigned* __restrict__ counter) {
+    constexpr int G = B2_G, W = B2_W, RB = BR_RB;
+    __shared__ T rowbuf[BR_HMAX * K];
+    __shared__ T colacc[G * W * K];
+    __shared__ unsigned next_ticket;
+    const SymLayout& L = B.L;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lane_off = (unsigned)lane * 16u;
+    int64_t q = 0, before = 0;
+    int64_t id = blockIdx.x;
+    while (id < total_items) {
+        unsigned ticket = 0;
+        if (tid == 0) ticket = atomicAdd(counter, 1u);
+        for (;;) {
+            const int64_t cnt = (B.grp_rows(q) + B.H - 1) / B.H;
+            if (id < before + cnt) break;
+            before += cnt;
+            ++q;
+        }
+        const int64_t chunk = id - before;
+        const int64_t grows = uniform64(B.grp_rows(q));
+        const int64_t r_lo = uniform64(chunk * (int64_t)B.H);
+        const int64_t r_hi = r_lo + B.H < grows ? r_lo + B.H : grows;
+        const float* base[G];
+        int64_t lim[G], diag[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int64_t t = q * G + g;
+            const bool valid = t < B.T_loc;
+            const int64_t rows = valid ? L.rows(t) : 0;
+            lim[g] = uniform64(rows < r_hi ? rows : r_hi);
+            diag[g] = uniform64(valid ? L.strip(t) * W : 0);
+            base[g] = Kp + uniform64(valid ? L.row_offset(t) * W : 0);
+        }
+        // this lane's 4 columns of every strip and their right-hand-side entries
+        T vj[G][4][K], col[G][4][K];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t j = diag[g] + lane * 4 + e;
+#pragma unroll
+                for (int c = 0; c < K; ++c) {
+                    vj[g][e][c] = (lim[g] > 0 && j < L.n) ? V[j * ldv + c] : T(0);
+                    col[g][e][c] = T(0);
+                }
+            }
+        const int nb_item = (int)((r_hi - r_lo + RB - 1) / RB);
+        const int nbw = wave < nb_item ? (nb_item - wave + 3) / 4 : 0;
+        float4 stA[RB][G], stB[RB][G];
+        T vA, vB;
+        auto fetch = [&](float4 (&a)[RB][G], T& vi, int b) {
+            const int64_t i0 = r_lo + (int64_t)(b * 4 + wave) * RB;
+            {
+                const int e = lane < RB * K ? lane : RB * K - 1;
+                int64_t i = i0 + e / K;
+                if (i > r_hi - 1) i = r_hi - 1;
+                vi = V[i * ldv + e % K];
+            }
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int64_t i = i0 + r;
+                    const bool part = i < lim[g];  // wave-uniform; absent rows read one cached row and are skipped below
+                    a[r][g] = load_stream_at<float4>((part ? base[g] : Kp) + (part ? i : 0) * W, lane_off);
+                }
+        };
+        auto consume = [&](const float4 (&a)[RB][G], T vi, int b) {
+            const int64_t i0 = r_lo + (int64_t)(b * 4 + wave) * RB;
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int64_t i = i0 + r;
+                T dot[K];
+#pragma unroll
+                for (int c = 0; c < K; ++c) dot[c] = T(0);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (i < lim[g]) {  // (wave-uniform)
+                        const T ae[4] = {(T)a[r][g].x, (T)a[r][g].y, (T)a[r][g].z, (T)a[r][g].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int c = 0; c < K; ++c) dot[c] += ae[e] * vj[g][e][c];
+                        if (i < diag[g]) {
+#pragma unroll
+                            for (int c = 0; c < K; ++c) {
+                                const T vic = lane_value(vi, r * K + c);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) col[g][e][c] += ae[e] * vic;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < K; ++c) {
+                    const T tot = wave_total_lane63(dot[c]);
+                    if (lane == 63 && i < r_hi) rowbuf[(i - r_lo) * K + c] = tot;
+                }
+            }
+        };
+        if (nbw > 0) {
+            int b = 0;
+            fetch(stA, vA, b);
+            for (;;) {
+                if (b + 1 >= nbw) { consume(stA, vA, b); break; }
+                fetch(stB, vB, b + 1);
+                consume(stA, vA, b);
+                ++b;
+                if (b + 1 >= nbw) { consume(stB, vB, b); break; }
+                fetch(stA, vA, b + 1);
+                consume(stB, vB, b);
+                ++b;
+            }
+        }
+        __syncthreads();  // the item's row sums are in rowbuf
+        T* pr = Prow + (B.prow_off(q) + r_lo) * K;
+        for (int e = tid; e < (int)(r_hi - r_lo) * K; e += BR_THREADS) __builtin_nontemporal_store(rowbuf[e], &pr[e]);
+        // column sums: the four waves add theirs in a fixed order (bitwise reproducible)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int c = 0; c < K; ++c) {
+                            const int at = ((g * W) + lane * 4 + e) * K + c;
+                            colacc[at] = w == 0 ? col[g][e][c] : colacc[at] + col[g][e][c];
+                        }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (r_lo < diag[g]) {
+                T* pc = Pcol + (((q * B.max_chunks + chunk) * G + g) * W) * K;
+                for (int e = tid; e < W * K; e += BR_THREADS) __builtin_nontemporal_store(colacc[g * W * K + e], &pc[e]);
+            }
+        }
+        if (tid == 0) next_ticket = ticket;
+        __syncthreads();  // rowbuf / colacc are reused by the next item
+        id = (int64_t)gridDim.x + __builtin_amdgcn_readfirstlane(next_ticket);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(1024)
+symm_blk_finish_t_kernel(BlkLayout B, int K, const T* __restrict__ Prow, const T* __restrict__ Pcol, T alpha, T shift,
+                         const T* __restrict__ V, int64_t ldv, T* __restrict__ Y, int64_t ldy) {
+    constexpr int NS = 16;
+    __shared__ T red[NS][64];
+    const SymLayout& L = B.L;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + tx;
+    const bool live = e < L.n * K;
+    T sum = T(0);
+    int64_t i = 0;
+    int c = 0;
+    if (live) {
+        i = e / K;
+        c = (int)(e - i * K);
+        const int64_t blk = i / B2_W;
+        const int64_t t0 = blk <= L.first ? 0 : (blk - L.first + L.stride - 1) / L.stride;
+        const int64_t q0 = t0 / B2_G;
+        const int64_t nrow = (t0 < B.T_loc && B.Q > q0) ? B.Q - q0 : 0;
+        int64_t qc = 0, gc = 0, ncol = 0;
+        if (blk >= L.first && (blk - L.first) % L.stride == 0) {
+            const int64_t tc = (blk - L.first) / L.stride;
+            qc = tc / B2_G;
+            gc = tc - qc * B2_G;
+            ncol = (blk * B2_W + B.H - 1) / B.H;
+        }
+        const int64_t jloc = i - blk * B2_W;
+        auto term = [&](int64_t u) -> T {
+            return u < nrow ? Prow[(B.prow_off(q0 + u) + i) * K + c]
+                            : Pcol[(((qc * B.max_chunks + (u - nrow)) * B2_G + gc) * B2_W + jloc) * K + c];
+        };
+        T s4[4] = {T(0), T(0), T(0), T(0)};
+        int64_t u = ty;
+        for (; u + 3 * NS < nrow + ncol; u += 4 * NS) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) s4[w] += term(u + w * NS);
+        }
+        for (int w = 0; u < nrow + ncol; u += NS, ++w) s4[w] += term(u);
+        sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    }
+    red[ty][tx] = sum;
+    __syncthreads();
+    if (ty == 0 && live) {
+        sum = T(0);
+#pragma unroll
+        for (int y = 0; y < NS; ++y) sum += red[y][tx];
+        T y = alpha * sum;
+        if (shift != T(0)) y += shift * V[i * ldv + c];
+        Y[i * ldy + c] = y;
+    }
+}
+
 static int64_t device_cus() {
     static std::atomic<int> cu_count[64];
     int dev = 0;
@@ -484,5 +702,62 @@ int symm_matmat_h2blk_impl(const float* Kp, int64_t n, int64_t first, int64_t st
                        Pcol, (float)alpha, (float)shift, V, ldv, Y, ldy, reinterpret_cast<const float*>(info + 32));
     return launch_status("rk_symm_matmat_f16x2(finish)");
 }
+
+// ---- the vector-unit block kernel: float32 storage, float32 / float64 vectors, 1 .. 4 columns ------------------------
+template <typename T>
+static BlkLayout blkreg_layout(int64_t n, int64_t k, int64_t first, int64_t stride) {
+    const int wg = (sizeof(T) == 8 || k > 1) ? 2 : 3;  // resident workgroups per CU (141 / 201-213 registers)
+    return make_blk_layout(n, first, stride, device_cus() * wg, BR_HMAX);
+}
+
+template <typename T>
+size_t symm_blkreg_ws_bytes(int64_t n, int64_t k, int64_t first, int64_t stride) {
+    const BlkLayout B = blkreg_layout<T>(n, k, first, stride);
+    const size_t prow = (size_t)round_up(B.prow_rows() * k, 4) * sizeof(T);
+    const size_t pcol = (size_t)B.Q * B.max_chunks * B2_G * B2_W * k * sizeof(T);
+    return 256 + prow + pcol;
+}
+template size_t symm_blkreg_ws_bytes<float>(int64_t, int64_t, int64_t, int64_t);
+template size_t symm_blkreg_ws_bytes<double>(int64_t, int64_t, int64_t, int64_t);
+
+template <typename T>
+int symm_matmat_blkreg_impl(const float* Kp, int64_t n, int64_t first, int64_t stride, const T* V, int64_t k, int64_t ldv,
+                            double alpha, double shift, T* Y, int64_t ldy, void* ws, size_t ws_bytes, hipStream_t st) {
+    const BlkLayout B = blkreg_layout<T>(n, k, first, stride);
+    const size_t need = symm_blkreg_ws_bytes<T>(n, k, first, stride);
+    if (ws == nullptr || ws_bytes < need) {
+        set_error("rk_symm_matmat: workspace %zu B < required %zu B", ws_bytes, need);
+        return RK_ERR_WORKSPACE;
+    }
+    unsigned* counter = static_cast<unsigned*>(ws);
+    T* Prow = reinterpret_cast<T*>(static_cast<char*>(ws) + 256);
+    T* Pcol = Prow + (size_t)round_up(B.prow_rows() * k, 4);
+    if (hipMemsetAsync(counter, 0, 256, st) != hipSuccess) return launch_status("rk_symm_matmat(memset)");
+    if (B.T_loc > 0) {
+        const int64_t total_items = blk_items(B);
+        const int wg = (sizeof(T) == 8 || k > 1) ? 2 : 3;
+        const int64_t resident = device_cus() * wg;
+        dim3 grid((unsigned)(total_items < resident ? total_items : resident));
+#define RK_BR(KK)                                                                                              \
+    hipLaunchKernelGGL((symm_blk_reg_kernel<T, KK>), grid, dim3(BR_THREADS), 0, st, Kp, B, V, ldv, Prow, Pcol, \
+                       total_items, counter)
+        switch (k) {
+            case 1: RK_BR(1); break;
+            case 2: RK_BR(2); break;
+            case 3: RK_BR(3); break;
+            default: RK_BR(4); break;
+        }
+#undef RK_BR
+        int rc = launch_status("rk_symm_matmat(block)");
+        if (rc != RK_OK) return rc;
+    }
+    hipLaunchKernelGGL((symm_blk_finish_t_kernel<T>), dim3((unsigned)ceil_div(n * k, 64)), dim3(1024), 0, st, B, (int)k,
+                       Prow, Pcol, (T)alpha, (T)shift, V, ldv, Y, ldy);
+    return launch_status("rk_symm_matmat(finish)");
+}
+template int symm_matmat_blkreg_impl<float>(const float*, int64_t, int64_t, int64_t, const float*, int64_t, int64_t, double,
+                                            double, float*, int64_t, void*, size_t, hipStream_t);
+template int symm_matmat_blkreg_impl<double>(const float*, int64_t, int64_t, int64_t, const double*, int64_t, int64_t,
+                                             double, double, double*, int64_t, void*, size_t, hipStream_t);
 
 }  // namespace rk

@@ -316,9 +316,8 @@ class HipBackend:
         """alpha * (this rank's partial of) K V + diag_shift * V from the packed triangle; the
         arithmetic type is V's dtype, the storage type Kp's (float32 storage under float64 V).
         ``kmax``: a bound on the magnitude of the stored entries (the operator's const_scaling) - with it,
-        float32 products of RK_SYMM_F16X2_MIN (1) .. 16 columns run on the 16-bit matrix cores
-        (``rk_symm_matmat_f16x2``; since round 4 its block form is faster than the float32 register kernel at
-        every width: n = 200 000, k = 1: 12.03 against 12.35 ms on the same card)."""
+        float32 products of RK_SYMM_F16X2_MIN (3) .. 16 columns run on the 16-bit matrix cores
+        (``rk_symm_matmat_f16x2``, block form)."""
         dev = _req(Kp, V)
         V2, squeeze = _as2d(V)
         if V2.shape[0] != n:
@@ -329,12 +328,11 @@ class HipBackend:
         k = V2.shape[1]
         out = torch.empty((n, k), dtype=V2.dtype, device=dev)
         es = V2.element_size()
-        # (one column over a small shard - the per-rank shape of an 8-GPU run, 10 GB - stays with the float32 register
-        # kernel: 1.55 against 1.69 ms; the block kernel's fixed costs amortise from ~25 GB on: 40 GB 5.90 against 6.15 ms,
-        # 80 GB 11.55 against 12.37 ms)
-        small_single = k == 1 and Kp.numel() * 4 < int(float(os.environ.get("RK_SYMM_F16X2_MIN_BYTES", "24e9")))
-        if (kmax is not None and kmax > 0 and V2.dtype == torch.float32 and Kp.dtype == torch.float32 and not small_single
-                and k >= int(os.environ.get("RK_SYMM_F16X2_MIN", "1")) and os.environ.get("RK_SYMM_F16X2", "1") != "0"):
+        # one or two columns run the block decomposition on the vector units (rk_symm_matmat -> symm_blk_reg_kernel: exact
+        # float32 arithmetic, no split prologue; as fast as the matrix-core form at 80 GB - 11.6 ms - and faster on
+        # small shards: 1.57 against 1.63 ms at 10 GB); from three columns on the 16-bit matrix cores take over
+        if (kmax is not None and kmax > 0 and V2.dtype == torch.float32 and Kp.dtype == torch.float32
+                and k >= int(os.environ.get("RK_SYMM_F16X2_MIN", "3")) and os.environ.get("RK_SYMM_F16X2", "1") != "0"):
             for c0 in range(0, k, 16):
                 kc = min(16, k - c0)
                 ws, wsn = self._workspace(dev, self._lib.rk_symm_matmat_f16x2_ws_bytes(n, kc, first, stride))

@@ -120,7 +120,7 @@ def test_block_symmetric_product_and_fused_sketch_random_shapes(be, monkeypatch,
     blocks - each against the float64 oracle."""
     rng = random.Random(4000 + seed)
     gen = torch.Generator().manual_seed(seed)
-    monkeypatch.setenv("RK_SYMM_F16X2_MIN_BYTES", "0")
+    monkeypatch.setenv("RK_SYMM_F16X2_MIN", "1")  # (one or two columns would take the vector-unit block kernel: below)
     n = _near(rng, [1, 33, 256, 257, 1024, 1025, 2048, 3100, 5121], 2)
     d = rng.choice([3, 16, 40, 64])
     k = rng.choice([1, 2, 3, 5, 8, 11, 16])
@@ -139,6 +139,19 @@ def test_block_symmetric_product_and_fused_sketch_random_shapes(be, monkeypatch,
                                 kmax=scale).cpu().double()
     err = (total - want).norm(dim=0) / want.norm(dim=0)
     assert float(err.max()) < 5e-6, (n, d, k, stride, kind, float(err.max()))
+    # the vector-unit block kernel (exact float32 arithmetic; what one or two columns run by default), and the same with
+    # float64 vectors over the float32 strips
+    monkeypatch.delenv("RK_SYMM_F16X2_MIN")
+    k2 = min(k, 2)
+    for vdt in (torch.float32, torch.float64):
+        tot2 = torch.zeros(n, k2, dtype=torch.float64)
+        Vv = V[:, :k2].to(vdt).contiguous().to(DEV)
+        for f in range(stride):
+            Kp = be.sympack_materialize(kind, Xd, 1.1, scale=scale, first=f, stride=stride)
+            tot2 += be.symm_matmat(Kp, n, Vv, diag_shift=0.5 if f == 0 else 0.0, first=f, stride=stride,
+                                   kmax=scale).cpu().double()
+        err2 = (tot2 - want[:, :k2]).norm(dim=0) / want[:, :k2].norm(dim=0)
+        assert float(err2.max()) < (5e-6 if vdt == torch.float32 else 2e-7), (n, d, k2, stride, kind, vdt, float(err2.max()))
     # the fused sketch product on the same points against a second, rectangular set
     n2 = _near(rng, [31, 129, 700, 1500], 3)
     r = rng.choice([17, 64, 130, 257, 600])

@@ -975,7 +975,7 @@ def test_symm_matmat_f16x2_matrix_core_strip_product(be, n, k, first, stride):
     for f in range(stride):
         Kp = be.sympack_materialize("matern32", Xd, 0.9, scale=scale, first=f, stride=stride)
         import os as _os
-        _os.environ["RK_SYMM_F16X2_MIN_BYTES"] = "0"  # (a single column over a small matrix would take the register kernel)
+        _os.environ["RK_SYMM_F16X2_MIN"] = "1"  # (one or two columns would take the vector-unit block kernel)
         got = be.symm_matmat(Kp, n, Vd, alpha=-1.5, diag_shift=0.25 if f == 0 else 0.0, first=f, stride=stride,
                              kmax=scale)
         again = be.symm_matmat(Kp, n, Vd, alpha=-1.5, diag_shift=0.25 if f == 0 else 0.0, first=f, stride=stride,
@@ -988,7 +988,7 @@ def test_symm_matmat_f16x2_matrix_core_strip_product(be, n, k, first, stride):
                                    kmax=scale)
         finally:
             del _os.environ["RK_SYMM_H2_IMPL"]
-            del _os.environ["RK_SYMM_F16X2_MIN_BYTES"]
+            del _os.environ["RK_SYMM_F16X2_MIN"]
         if stride == 1:
             assert float(((got - strip).double().norm(dim=0) / strip.double().norm(dim=0)).max()) < 3e-6
         parts.append(got.cpu().double())

@@ -221,10 +221,23 @@ def test_fullsize_packed_symmetric_product(be, full_problem):
     # one right-hand side, and symmetry of the bilinear form through the packed operator
     y1 = be.symm_matmat(Kp, n, vd[:, 0].contiguous(), diag_shift=reg)
     assert float((y1 - y[:, 0]).norm() / y[:, 0].norm()) < 1e-5
-    # the same column through the block kernel on the 16-bit matrix cores - what the PCG loop runs at this size (the
-    # operator passes the bound on its entries): the float32 kernel's result, the oracle's rows, bit for bit repeatable
-    y1h = be.symm_matmat(Kp, n, vd[:, 0].contiguous(), diag_shift=reg, kmax=1.0)
-    assert torch.equal(y1h, be.symm_matmat(Kp, n, vd[:, 0].contiguous(), diag_shift=reg, kmax=1.0))
+    # the same column through the block kernel on the 16-bit matrix cores (RK_SYMM_F16X2_MIN=1; by default one or two
+    # columns run the vector-unit block kernel - the product above): the float32 result, the oracle's rows, bit for bit
+    # repeatable
+    import os as _os
+    _os.environ["RK_SYMM_F16X2_MIN"] = "1"
+    try:
+        y1h = be.symm_matmat(Kp, n, vd[:, 0].contiguous(), diag_shift=reg, kmax=1.0)
+        assert torch.equal(y1h, be.symm_matmat(Kp, n, vd[:, 0].contiguous(), diag_shift=reg, kmax=1.0))
+    finally:
+        del _os.environ["RK_SYMM_F16X2_MIN"]
+    # ... and the round-3 strip kernel the vector-unit block kernel replaced (RK_SYMM_BLKREG=0)
+    _os.environ["RK_SYMM_BLKREG"] = "0"
+    try:
+        y1s = be.symm_matmat(Kp, n, vd[:, 0].contiguous(), diag_shift=reg)
+    finally:
+        del _os.environ["RK_SYMM_BLKREG"]
+    assert float((y1s - y1).norm() / y1.norm()) < 1e-5
     assert float((y1h - y1).norm() / y1.norm()) < 1e-5
     assert float((y1h[rows.to(DEV)].cpu() - want[:, 0]).norm() / want[:, 0].norm()) < 2e-5
     ud = u.to(DEV)

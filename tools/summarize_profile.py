@@ -44,11 +44,12 @@ bench = json.loads([l for l in open(f"{src}/{tag}_bench_n1.log") if l.startswith
 storage = bench["roofline"].get("storage", "materialize")
 kdesc = bench["roofline"].get("kernel", "")
 if storage.startswith("sympack"):
-    KNAME = "symm_blk_h2_kernel" if "symm_blk_h2_kernel" in kdesc else "symm_strip_kernel<float, float, 1>"
+    KNAME = ("symm_blk_reg_kernel" if "symm_blk_reg_kernel" in kdesc else
+             "symm_blk_h2_kernel" if "symm_blk_h2_kernel" in kdesc else "symm_strip_kernel<float, float, 1>")
 else:
     KNAME = "skinny_nn_kernel<float, 1, 8"
 # the product's second launch (it reads the partial tables the first one wrote): its traffic belongs to the product
-FINISH = {"symm_blk_h2_kernel": "symm_blk_finish_kernel", "symm_strip_kernel<float, float, 1>": "symm_finish_kernel<float>"}.get(KNAME)
+FINISH = {"symm_blk_reg_kernel": "symm_blk_finish_t_kernel", "symm_blk_h2_kernel": "symm_blk_finish_kernel", "symm_strip_kernel<float, float, 1>": "symm_finish_kernel<float>"}.get(KNAME)
 
 
 def pmc(kind):
