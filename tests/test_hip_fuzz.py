@@ -151,7 +151,8 @@ def test_block_symmetric_product_and_fused_sketch_random_shapes(be, monkeypatch,
             tot2 += be.symm_matmat(Kp, n, Vv, diag_shift=0.5 if f == 0 else 0.0, first=f, stride=stride,
                                    kmax=scale).cpu().double()
         err2 = (tot2 - want[:, :k2]).norm(dim=0) / want[:, :k2].norm(dim=0)
-        assert float(err2.max()) < (5e-6 if vdt == torch.float32 else 2e-7), (n, d, k2, stride, kind, vdt, float(err2.max()))
+        # (float64 vectors: what remains is the float32 rounding of the STORED entries, evaluated in float32 from float32 data)
+        assert float(err2.max()) < (5e-6 if vdt == torch.float32 else 2e-6), (n, d, k2, stride, kind, vdt, float(err2.max()))
     # the fused sketch product on the same points against a second, rectangular set
     n2 = _near(rng, [31, 129, 700, 1500], 3)
     r = rng.choice([17, 64, 130, 257, 600])
