@@ -98,11 +98,11 @@ int symm_matmat_h2blk_impl(const float* Kp, int64_t n, int64_t first, int64_t st
                            int64_t k, int64_t ldv, double alpha, double shift, float* Y, int64_t ldy, void* ws,
                            size_t ws_bytes, hipStream_t st);
 
-// the vector-unit block kernel (rk_symmblk.hip): float32 storage, T = float / double vectors, k <= 4
-template <typename T>
+// the vector-unit block kernel (rk_symmblk.hip): storage TS, vectors T (float/float, float/double, double/double), k <= 2
+template <typename TS, typename T>
 size_t symm_blkreg_ws_bytes(int64_t n, int64_t k, int64_t first, int64_t stride);
-template <typename T>
-int symm_matmat_blkreg_impl(const float* Kp, int64_t n, int64_t first, int64_t stride, const T* V, int64_t k, int64_t ldv,
+template <typename TS, typename T>
+int symm_matmat_blkreg_impl(const TS* Kp, int64_t n, int64_t first, int64_t stride, const T* V, int64_t k, int64_t ldv,
                             double alpha, double shift, T* Y, int64_t ldy, void* ws, size_t ws_bytes, hipStream_t st);
 
 }  // namespace rk

@@ -1148,10 +1148,11 @@ extern "C" size_t rk_symm_matmat_ws_bytes(int dtype, int store_dtype, int64_t n,
     auto both = [](size_t a, size_t b) { return a > b ? a : b; };  // (either implementation can run in it)
     if (dtype == RK_F32)
         return both(symm_ws_bytes<float, float>(n, k, strip_first, strip_stride),
-                    symm_blkreg_ws_bytes<float>(n, k, strip_first, strip_stride));
+                    symm_blkreg_ws_bytes<float, float>(n, k, strip_first, strip_stride));
     return store_dtype == RK_F32 ? both(symm_ws_bytes<float, double>(n, k, strip_first, strip_stride),
-                                        symm_blkreg_ws_bytes<double>(n, k, strip_first, strip_stride))
-                                 : symm_ws_bytes<double, double>(n, k, strip_first, strip_stride);
+                                        symm_blkreg_ws_bytes<float, double>(n, k, strip_first, strip_stride))
+                                 : both(symm_ws_bytes<double, double>(n, k, strip_first, strip_stride),
+                                        symm_blkreg_ws_bytes<double, double>(n, k, strip_first, strip_stride));
 }
 
 extern "C" int rk_symm_matmat(int dtype, int store_dtype, const void* Kp, int64_t n,
@@ -1176,16 +1177,18 @@ extern "C" int rk_symm_matmat(int dtype, int store_dtype, const void* Kp, int64_
         return symm_matmat_wide_impl<double>((const double*)Kp, n, strip_first, strip_stride, (const double*)V, k,
                                              ldv, alpha, diag_shift, (double*)Y, ldy, ws, ws_bytes, st);
     }
-    // float32 storage, at most 4 columns: the block decomposition on the vector units (rk_symmblk.hip; RK_SYMM_BLKREG=0:
-    // the strip kernel)
-    // (one or two float32 columns, one float64 column: beyond that the per-lane column sums of four strips do not fit
-    // the registers at a useful occupancy)
-    if (store_dtype == RK_F32 && symm_use_blkreg() && k <= (dtype == RK_F32 ? 2 : 1)) {
+    // one or two float32 columns, one float64 column (over float32 or float64 storage): the block decomposition on the
+    // vector units (rk_symmblk.hip; RK_SYMM_BLKREG=0: the strip kernel).  Beyond that the per-lane column sums of four
+    // strips do not fit the registers at a useful occupancy.
+    if (symm_use_blkreg() && k <= (dtype == RK_F32 ? 2 : 1)) {
         if (dtype == RK_F32)
-            return symm_matmat_blkreg_impl<float>((const float*)Kp, n, strip_first, strip_stride, (const float*)V, k, ldv,
-                                                  alpha, diag_shift, (float*)Y, ldy, ws, ws_bytes, st);
-        return symm_matmat_blkreg_impl<double>((const float*)Kp, n, strip_first, strip_stride, (const double*)V, k, ldv,
-                                               alpha, diag_shift, (double*)Y, ldy, ws, ws_bytes, st);
+            return symm_matmat_blkreg_impl<float, float>((const float*)Kp, n, strip_first, strip_stride, (const float*)V,
+                                                         k, ldv, alpha, diag_shift, (float*)Y, ldy, ws, ws_bytes, st);
+        if (store_dtype == RK_F32)
+            return symm_matmat_blkreg_impl<float, double>((const float*)Kp, n, strip_first, strip_stride, (const double*)V,
+                                                          k, ldv, alpha, diag_shift, (double*)Y, ldy, ws, ws_bytes, st);
+        return symm_matmat_blkreg_impl<double, double>((const double*)Kp, n, strip_first, strip_stride, (const double*)V, k,
+                                                       ldv, alpha, diag_shift, (double*)Y, ldy, ws, ws_bytes, st);
     }
     if (dtype == RK_F32)
         return symm_matmat_impl<float, float>((const float*)Kp, n, strip_first, strip_stride,

@@ -81,7 +81,7 @@ struct BlkLayout {
     }
     // table rows before group q (every earlier group is complete and unclipped)
     __host__ __device__ int64_t prow_off(int64_t q) const {
-        return (int64_t)B2_W * (q * (L.first + 1 + (B2_G - 1) * L.stride) + B2_G * L.stride * (q * (q - 1) / 2));
+        return (int64_t)L.W * (q * (L.first + 1 + (B2_G - 1) * L.stride) + B2_G * L.stride * (q * (q - 1) / 2));
     }
     __host__ __device__ int64_t prow_rows() const { return Q ? prow_off(Q - 1) + grp_rows(Q - 1) : 0; }
 };
@@ -102,7 +102,7 @@ static int pick_item_rows(BlkLayout B, int64_t cus, int hmax) {
     struct Key { int64_t n, first, stride, cus; int h; };
     static thread_local Key cache[8] = {};
     for (const Key& c : cache)
-        if (c.h && c.n == B.L.n && c.first == B.L.first && c.stride == B.L.stride && c.cus == cus + 100000 * (int64_t)hmax) return c.h;
+        if (c.h && c.n == B.L.n && c.first == B.L.first && c.stride == B.L.stride && c.cus == cus + 100000 * (int64_t)hmax + 50000 * (B.L.W == 128)) return c.h;
     double best = 1e300;
     int best_h = 256;
     for (int h = hmax; h >= 256; h -= 32) {
@@ -113,14 +113,15 @@ static int pick_item_rows(BlkLayout B, int64_t cus, int hmax) {
         if (cost < best) { best = cost; best_h = h; }
     }
     static thread_local int next = 0;
-    cache[next] = Key{B.L.n, B.L.first, B.L.stride, cus + 100000 * (int64_t)hmax, best_h};
+    cache[next] = Key{B.L.n, B.L.first, B.L.stride, cus + 100000 * (int64_t)hmax + 50000 * (B.L.W == 128), best_h};
     next = (next + 1) % 8;
     return best_h;
 }
 
-static BlkLayout make_blk_layout(int64_t n, int64_t first, int64_t stride, int64_t cus = 256, int hmax = 2048) {
+static BlkLayout make_blk_layout(int64_t n, int64_t first, int64_t stride, int64_t cus = 256, int hmax = 2048,
+                                 bool f64_storage = false) {
     BlkLayout B;
-    B.L = make_layout<float>(n, first, stride);
+    B.L = f64_storage ? make_layout<double>(n, first, stride) : make_layout<float>(n, first, stride);
     B.T_loc = B.L.strips_local();
     B.Q = ceil_div(B.T_loc, B2_G);
     B.H = B2_H_FIXED;
@@ -429,13 +430,15 @@ constexpr int BR_RB = 2;        // rows per batch: 8 loads of 1 KiB per stage, t
 constexpr int BR_HMAX = 1024;   // rows per item at most (the row sums of an item wait in LDS)
 constexpr int BR_THREADS = 256;
 
-template <typename T, int K>
+template <typename TS, typename T, int K>
 __global__ void __launch_bounds__(BR_THREADS)
-symm_blk_reg_kernel(const float* __restrict__ Kp, BlkLayout B, const T* __restrict__ V, int64_t ldv,
+symm_blk_reg_kernel(const TS* __restrict__ Kp, BlkLayout B, const T* __restrict__ V, int64_t ldv,
                     T* __restrict__ Prow, T* __restrict__ Pcol, int64_t total_items, unsigned* __restrict__ counter) {
-    constexpr int G = B2_G, W = B2_W, RB = BR_RB;
+    using V16 = typename Vec16<TS>::type;
+    constexpr int VW = Vec16<TS>::N;  // stored entries per 16-byte load: 4 / 2
+    constexpr int G = B2_G, W = 64 * VW, RB = BR_RB;
     __shared__ T rowbuf[BR_HMAX * K];
-    __shared__ T colacc[G * W * K];
+    __shared__ T colacc[B2_G * 64 * (16 / sizeof(TS)) * K];
     __shared__ unsigned next_ticket;
     const SymLayout& L = B.L;
     const int tid = threadIdx.x;
@@ -457,7 +460,7 @@ symm_blk_reg_kernel(const float* __restrict__ Kp, BlkLayout B, const T* __restri
         const int64_t grows = uniform64(B.grp_rows(q));
         const int64_t r_lo = uniform64(chunk * (int64_t)B.H);
         const int64_t r_hi = r_lo + B.H < grows ? r_lo + B.H : grows;
-        const float* base[G];
+        const TS* base[G];
         int64_t lim[G], diag[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -469,12 +472,12 @@ symm_blk_reg_kernel(const float* __restrict__ Kp, BlkLayout B, const T* __restri
             base[g] = Kp + uniform64(valid ? L.row_offset(t) * W : 0);
         }
         // this lane's 4 columns of every strip and their right-hand-side entries
-        T vj[G][4][K], col[G][4][K];
+        T vj[G][VW][K], col[G][VW][K];
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int64_t j = diag[g] + lane * 4 + e;
+            for (int e = 0; e < VW; ++e) {
+                const int64_t j = diag[g] + lane * VW + e;
 #pragma unroll
                 for (int c = 0; c < K; ++c) {
                     vj[g][e][c] = (lim[g] > 0 && j < L.n) ? V[j * ldv + c] : T(0);
@@ -483,9 +486,9 @@ symm_blk_reg_kernel(const float* __restrict__ Kp, BlkLayout B, const T* __restri
             }
         const int nb_item = (int)((r_hi - r_lo + RB - 1) / RB);
         const int nbw = wave < nb_item ? (nb_item - wave + 3) / 4 : 0;
-        float4 stA[RB][G], stB[RB][G];
+        V16 stA[RB][G], stB[RB][G];
         T vA, vB;
-        auto fetch = [&](float4 (&a)[RB][G], T& vi, int b) {
+        auto fetch = [&](V16 (&a)[RB][G], T& vi, int b) {
             const int64_t i0 = r_lo + (int64_t)(b * 4 + wave) * RB;
             {
                 const int e = lane < RB * K ? lane : RB * K - 1;
@@ -499,10 +502,10 @@ symm_blk_reg_kernel(const float* __restrict__ Kp, BlkLayout B, const T* __restri
                 for (int g = 0; g < G; ++g) {
                     const int64_t i = i0 + r;
                     const bool part = i < lim[g];  // wave-uniform; absent rows read one cached row and are skipped below
-                    a[r][g] = load_stream_at<float4>((part ? base[g] : Kp) + (part ? i : 0) * W, lane_off);
+                    a[r][g] = load_stream_at<V16>((part ? base[g] : Kp) + (part ? i : 0) * W, lane_off);
                 }
         };
-        auto consume = [&](const float4 (&a)[RB][G], T vi, int b) {
+        auto consume = [&](const V16 (&a)[RB][G], T vi, int b) {
             const int64_t i0 = r_lo + (int64_t)(b * 4 + wave) * RB;
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
@@ -513,9 +516,12 @@ symm_blk_reg_kernel(const float* __restrict__ Kp, BlkLayout B, const T* __restri
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
                     if (i < lim[g]) {  // (wave-uniform)
-                        const T ae[4] = {(T)a[r][g].x, (T)a[r][g].y, (T)a[r][g].z, (T)a[r][g].w};
+                        const TS* as = reinterpret_cast<const TS*>(&a[r][g]);
+                        T ae[VW];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
+                        for (int e = 0; e < VW; ++e) ae[e] = (T)as[e];
+#pragma unroll
+                        for (int e = 0; e < VW; ++e)
 #pragma unroll
                             for (int c = 0; c < K; ++c) dot[c] += ae[e] * vj[g][e][c];
                         if (i < diag[g]) {
@@ -523,7 +529,7 @@ symm_blk_reg_kernel(const float* __restrict__ Kp, BlkLayout B, const T* __restri
                             for (int c = 0; c < K; ++c) {
                                 const T vic = lane_value(vi, r * K + c);
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) col[g][e][c] += ae[e] * vic;
+                                for (int e = 0; e < VW; ++e) col[g][e][c] += ae[e] * vic;
                             }
                         }
                     }
@@ -559,10 +565,10 @@ symm_blk_reg_kernel(const float* __restrict__ Kp, BlkLayout B, const T* __restri
 #pragma unroll
                 for (int g = 0; g < G; ++g)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                    for (int e = 0; e < VW; ++e)
 #pragma unroll
                         for (int c = 0; c < K; ++c) {
-                            const int at = ((g * W) + lane * 4 + e) * K + c;
+                            const int at = ((g * W) + lane * VW + e) * K + c;
                             colacc[at] = w == 0 ? col[g][e][c] : colacc[at] + col[g][e][c];
                         }
             }
@@ -597,7 +603,8 @@ symm_blk_finish_t_kernel(BlkLayout B, int K, const T* __restrict__ Prow, const T
     if (live) {
         i = e / K;
         c = (int)(e - i * K);
-        const int64_t blk = i / B2_W;
+        const int W = L.W;
+        const int64_t blk = i / W;
         const int64_t t0 = blk <= L.first ? 0 : (blk - L.first + L.stride - 1) / L.stride;
         const int64_t q0 = t0 / B2_G;
         const int64_t nrow = (t0 < B.T_loc && B.Q > q0) ? B.Q - q0 : 0;
@@ -606,12 +613,12 @@ symm_blk_finish_t_kernel(BlkLayout B, int K, const T* __restrict__ Prow, const T
             const int64_t tc = (blk - L.first) / L.stride;
             qc = tc / B2_G;
             gc = tc - qc * B2_G;
-            ncol = (blk * B2_W + B.H - 1) / B.H;
+            ncol = (blk * W + B.H - 1) / B.H;
         }
-        const int64_t jloc = i - blk * B2_W;
+        const int64_t jloc = i - blk * W;
         auto term = [&](int64_t u) -> T {
             return u < nrow ? Prow[(B.prow_off(q0 + u) + i) * K + c]
-                            : Pcol[(((qc * B.max_chunks + (u - nrow)) * B2_G + gc) * B2_W + jloc) * K + c];
+                            : Pcol[(((qc * B.max_chunks + (u - nrow)) * B2_G + gc) * W + jloc) * K + c];
         };
         T s4[4] = {T(0), T(0), T(0), T(0)};
         int64_t u = ty;
@@ -703,28 +710,34 @@ int symm_matmat_h2blk_impl(const float* Kp, int64_t n, int64_t first, int64_t st
     return launch_status("rk_symm_matmat_f16x2(finish)");
 }
 
-// ---- the vector-unit block kernel: float32 storage, float32 / float64 vectors, 1 .. 4 columns ------------------------
-template <typename T>
+// ---- the vector-unit block kernel: float32 or float64 storage, vectors of the storage type or float64 over float32 -----
+// resident workgroups per CU by register count: one column of float / float and double / double 141 - 144 registers
+// (three waves per SIMD), everything else 201 - 211 (two)
+template <typename TS, typename T>
+static int blkreg_wgs(int64_t k) { return (k == 1 && sizeof(TS) == sizeof(T)) ? 3 : 2; }
+
+template <typename TS, typename T>
 static BlkLayout blkreg_layout(int64_t n, int64_t k, int64_t first, int64_t stride) {
-    const int wg = (sizeof(T) == 8 || k > 1) ? 2 : 3;  // resident workgroups per CU (141 / 201-213 registers)
-    return make_blk_layout(n, first, stride, device_cus() * wg, BR_HMAX);
+    const int wg = blkreg_wgs<TS, T>(k);
+    return make_blk_layout(n, first, stride, device_cus() * wg, BR_HMAX, sizeof(TS) == 8);
 }
 
-template <typename T>
+template <typename TS, typename T>
 size_t symm_blkreg_ws_bytes(int64_t n, int64_t k, int64_t first, int64_t stride) {
-    const BlkLayout B = blkreg_layout<T>(n, k, first, stride);
+    const BlkLayout B = blkreg_layout<TS, T>(n, k, first, stride);
     const size_t prow = (size_t)round_up(B.prow_rows() * k, 4) * sizeof(T);
-    const size_t pcol = (size_t)B.Q * B.max_chunks * B2_G * B2_W * k * sizeof(T);
+    const size_t pcol = (size_t)B.Q * B.max_chunks * B2_G * B.L.W * k * sizeof(T);
     return 256 + prow + pcol;
 }
-template size_t symm_blkreg_ws_bytes<float>(int64_t, int64_t, int64_t, int64_t);
-template size_t symm_blkreg_ws_bytes<double>(int64_t, int64_t, int64_t, int64_t);
+template size_t symm_blkreg_ws_bytes<float, float>(int64_t, int64_t, int64_t, int64_t);
+template size_t symm_blkreg_ws_bytes<float, double>(int64_t, int64_t, int64_t, int64_t);
+template size_t symm_blkreg_ws_bytes<double, double>(int64_t, int64_t, int64_t, int64_t);
 
-template <typename T>
-int symm_matmat_blkreg_impl(const float* Kp, int64_t n, int64_t first, int64_t stride, const T* V, int64_t k, int64_t ldv,
+template <typename TS, typename T>
+int symm_matmat_blkreg_impl(const TS* Kp, int64_t n, int64_t first, int64_t stride, const T* V, int64_t k, int64_t ldv,
                             double alpha, double shift, T* Y, int64_t ldy, void* ws, size_t ws_bytes, hipStream_t st) {
-    const BlkLayout B = blkreg_layout<T>(n, k, first, stride);
-    const size_t need = symm_blkreg_ws_bytes<T>(n, k, first, stride);
+    const BlkLayout B = blkreg_layout<TS, T>(n, k, first, stride);
+    const size_t need = symm_blkreg_ws_bytes<TS, T>(n, k, first, stride);
     if (ws == nullptr || ws_bytes < need) {
         set_error("rk_symm_matmat: workspace %zu B < required %zu B", ws_bytes, need);
         return RK_ERR_WORKSPACE;
@@ -735,19 +748,15 @@ int symm_matmat_blkreg_impl(const float* Kp, int64_t n, int64_t first, int64_t s
     if (hipMemsetAsync(counter, 0, 256, st) != hipSuccess) return launch_status("rk_symm_matmat(memset)");
     if (B.T_loc > 0) {
         const int64_t total_items = blk_items(B);
-        const int wg = (sizeof(T) == 8 || k > 1) ? 2 : 3;
+        const int wg = blkreg_wgs<TS, T>(k);
         const int64_t resident = device_cus() * wg;
         dim3 grid((unsigned)(total_items < resident ? total_items : resident));
-#define RK_BR(KK)                                                                                              \
-    hipLaunchKernelGGL((symm_blk_reg_kernel<T, KK>), grid, dim3(BR_THREADS), 0, st, Kp, B, V, ldv, Prow, Pcol, \
-                       total_items, counter)
-        switch (k) {
-            case 1: RK_BR(1); break;
-            case 2: RK_BR(2); break;
-            case 3: RK_BR(3); break;
-            default: RK_BR(4); break;
-        }
-#undef RK_BR
+        if (k == 1)
+            hipLaunchKernelGGL((symm_blk_reg_kernel<TS, T, 1>), grid, dim3(BR_THREADS), 0, st, Kp, B, V, ldv, Prow, Pcol,
+                               total_items, counter);
+        else
+            hipLaunchKernelGGL((symm_blk_reg_kernel<TS, T, 2>), grid, dim3(BR_THREADS), 0, st, Kp, B, V, ldv, Prow, Pcol,
+                               total_items, counter);
         int rc = launch_status("rk_symm_matmat(block)");
         if (rc != RK_OK) return rc;
     }
@@ -755,9 +764,11 @@ int symm_matmat_blkreg_impl(const float* Kp, int64_t n, int64_t first, int64_t s
                        Prow, Pcol, (T)alpha, (T)shift, V, ldv, Y, ldy);
     return launch_status("rk_symm_matmat(finish)");
 }
-template int symm_matmat_blkreg_impl<float>(const float*, int64_t, int64_t, int64_t, const float*, int64_t, int64_t, double,
-                                            double, float*, int64_t, void*, size_t, hipStream_t);
-template int symm_matmat_blkreg_impl<double>(const float*, int64_t, int64_t, int64_t, const double*, int64_t, int64_t,
-                                             double, double, double*, int64_t, void*, size_t, hipStream_t);
+template int symm_matmat_blkreg_impl<float, float>(const float*, int64_t, int64_t, int64_t, const float*, int64_t, int64_t,
+                                                   double, double, float*, int64_t, void*, size_t, hipStream_t);
+template int symm_matmat_blkreg_impl<float, double>(const float*, int64_t, int64_t, int64_t, const double*, int64_t,
+                                                    int64_t, double, double, double*, int64_t, void*, size_t, hipStream_t);
+template int symm_matmat_blkreg_impl<double, double>(const double*, int64_t, int64_t, int64_t, const double*, int64_t,
+                                                     int64_t, double, double, double*, int64_t, void*, size_t, hipStream_t);
 
 }  // namespace rk
