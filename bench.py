@@ -424,8 +424,7 @@ def main():
 
     mode = A.storage_mode
     # which kernel the timed products ran (decided here: the operator is released before the line is printed)
-    blk_kernel = bool(getattr(A, "_sym", None) is not None and A._sym.store_dtype == torch.float32
-                      and os.environ.get("RK_SYMM_BLKREG", "1") != "0")
+    blk_kernel = bool(getattr(A, "_sym", None) is not None and os.environ.get("RK_SYMM_BLKREG", "1") != "0")
     mv = timing.get("kernel_shard_product", {"avg_ms": float("nan"), "bytes_per_launch": 0, "launches": 0})
     achieved = mv["bytes_per_launch"] / (mv["avg_ms"] * 1e-3) / 1e9 if mv["launches"] else float("nan")
     if world > 1:  # roofline is per GPU: report the slowest rank's kernel
@@ -573,7 +572,8 @@ def main():
                 "kernel": (("rk_symm_matmat (symm_blk_reg_kernel + finish): strip-packed upper triangle, every stored entry "
                             "used for y[i] and y[j]; work items of four strips side by side x up to 1024 rows claimed from a "
                             "device counter, a row's partial sum carried across the strips (vector units, exact "
-                            + ("float32" if args.dtype == "f32" else "float64 over float32 storage") + " arithmetic); "
+                            + ("float32" if args.dtype == "f32" else
+                               ("float64" if args.storage == "same" else "float64 over float32 storage")) + " arithmetic); "
                             if blk_kernel else
                             "rk_symm_matmat (symm_strip_kernel + finish): strip-packed upper triangle, every stored entry "
                             "used for y[i] and y[j]; ") + "algorithmic bytes = packed triangle + V + Y"

@@ -1177,10 +1177,10 @@ extern "C" int rk_symm_matmat(int dtype, int store_dtype, const void* Kp, int64_
         return symm_matmat_wide_impl<double>((const double*)Kp, n, strip_first, strip_stride, (const double*)V, k,
                                              ldv, alpha, diag_shift, (double*)Y, ldy, ws, ws_bytes, st);
     }
-    // one or two float32 columns, one float64 column (over float32 or float64 storage): the block decomposition on the
+    // one or two columns of the storage type, one float64 column over float32 storage: the block decomposition on the
     // vector units (rk_symmblk.hip; RK_SYMM_BLKREG=0: the strip kernel).  Beyond that the per-lane column sums of four
     // strips do not fit the registers at a useful occupancy.
-    if (symm_use_blkreg() && k <= (dtype == RK_F32 ? 2 : 1)) {
+    if (symm_use_blkreg() && k <= ((dtype == RK_F32 || store_dtype == dtype) ? 2 : 1)) {
         if (dtype == RK_F32)
             return symm_matmat_blkreg_impl<float, float>((const float*)Kp, n, strip_first, strip_stride, (const float*)V,
                                                          k, ldv, alpha, diag_shift, (float*)Y, ldy, ws, ws_bytes, st);
