@@ -511,30 +511,37 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
 
 // ------------------------------------------------------------------------------------------------------------------
 // symgemm_ph_kernel: the same product (same tiles, same order of additions per accumulator: bitwise the results of
-// symgemm_kernel<SgF16>) with the step cut into four phases and the eight waves in two groups HALF A STEP APART.
+// symgemm_kernel<SgF16>) with the step cut into TWO phases and the eight waves in two groups HALF A STEP APART.
 //
 // symgemm_kernel's waves run in lockstep: one barrier per step, every wave stages (split + LDS stores), then every wave
-// reads operands, then every wave issues its 48 matrix-core instructions - the matrix cores wait while all eight stage
-// and read (50 % busy), and the two experiments that moved half the waves' code around inside the step made two
-// instruction streams (1.8 - 2.4 x slower).  Here every wave runs THE SAME code
-//     L0: operand reads (A, B columns 0 .. TN/4) + issue of the loads two steps ahead | barrier | M0: 24 matrix-core
-//     instructions | barrier | L1: operand reads (B columns TN/4 .. TN/2) + split and LDS store of the next K tile |
-//     barrier | M1: 24 matrix-core instructions (+ fold) | barrier
+// reads operands, then every wave issues its 48 matrix-core instructions.  Probes of this kernel's first form (four
+// phases per step; profiles/r04_symgemm_phases.log) showed what a step costs: the matrix-core work alone 63 ms, everything
+// else alone 77 ms - per step a chain of latencies (LDS-DMA issue ~75 - 150 cycles a piece, LDS round trips, barriers),
+// not throughput - and the two ADD UP unless one wave's chain runs beside its SIMD partner's matrix-core work.
+// Here every wave runs THE SAME code
+//     L(q): issue only: LDS store of K tile q + 1 (split in M(q - 1)), operand reads (A, two quarters of B), DMA of a V
+//           tile, loads of K tile q + 4                                                                 | barrier |
+//     M(q): 48 matrix-core instructions; between them the other two quarters of B (into the register sets of the
+//           first two) and the split of K tile q + 2; then the step's two waits                         | barrier |
 // and waves 4 - 7 pass ONE barrier more before their first step (waves 0 - 3 one more at the end): a SIMD holds one wave
-// of each group, so while one is in a phase M the other is in a phase L - the matrix cores see work in every interval
-// and the staging never competes with the other wave's staging.
-//   * V tiles: global_load_lds_dwordx4 (LDS-DMA) straight from the pre-split image into a ring of three LDS slots, two
-//     steps ahead; no registers, no ds_write (the LDS store path moved 32 KiB per step for them).
-//   * K tiles: registers as before (they are split on the way), but loaded by inline asm and waited for with a counted
-//     s_waitcnt: beside an LDS-DMA in flight the compiler waits vmcnt(0) for every ordinary load (the whole queue,
-//     every step).  Per wave and step the queue holds [K tile q + 2 (NA loads)] [V tile q + 2 (NBQ DMAs)], in this
-//     order; phase L1 of step q waits vmcnt(NA + NBQ): K tile and V tile q + 1 have landed, the newer pair stays in
-//     flight.  A landed DMA is read one barrier later at the earliest (the other group: two).
-//   * hazards (g0 / g1 = the groups, I_k = the interval between barriers k - 1 and k; g0 runs phase k in I_k, g1 in
-//     I_k+1):  K tile q + 1 is stored in L1(q) (I_4q+2 / I_4q+3; every wave waits lgkmcnt(0) before the barrier that ends
-//     the phase) into the buffer last read in L0(q - 1) (I_4q-4 / I_4q-3) and first read in L0(q + 1) (I_4q+4 / I_4q+5).
-//     The DMA of V tile q + 2 is issued in L0(q) (I_4q / I_4q+1) into the slot of tile q - 1, last read in L1(q - 1)
-//     (I_4q-2 / I_4q-1, retired by that phase's lgkmcnt(0)).  Operand reads are in registers before a phase M starts.
+// of each group, so one is in a phase M while the other is in a phase L.
+//   * V tiles: global_load_lds_dwordx4 (LDS-DMA) straight from the pre-split image into a ring of FOUR LDS slots (tile t
+//     in slot t % 4): no registers, no ds_write.  With the K-tile buffers that is all 160 KiB.
+//   * K tiles: registers (they are split on the way; tile t in register set t % 4, loaded four steps ahead), by inline
+//     asm with a counted s_waitcnt: beside an LDS-DMA in flight the compiler waits vmcnt(0) for every ordinary load.
+//     Every wait sits at the END of a phase M, behind its matrix-core instructions: queue of a wave there, oldest first,
+//     .. | V K(q+3) | V K(q+4) (what L(q - 1) and L(q) issued): vmcnt(NA + NBQ) = K tile q + 3 (split in M(q + 1)) and the
+//     older V tile have landed, what L(q) issued stays in flight.  A phase L only issues.
+//   * a group stages (splits, stores) the 64 rows of a K tile that its own waves read: the K tiles never cross groups.
+//   * hazards (g0 / g1 = the groups, I_k = the interval between barriers k - 1 and k; L(q) / M(q) are phases 2q / 2q + 1;
+//     g0 runs phase k in I_k, g1 in I_k+1; every wave waits lgkmcnt(0) before the barrier that ends a phase L, and all
+//     reads of a phase M are consumed inside it):
+//       K tile q + 2 -> buffer q % 2 in L(q + 1) (I_2q+2 / I_2q+3); that buffer was last read in L(q) (I_2q / I_2q+1) and
+//       is next read in L(q + 2) (I_2q+4 / I_2q+5).
+//       V tile t -> slot t % 4 by DMA: group 0 issues its share in L(t - 2) (I_2t-4), group 1 - one interval behind in
+//       everything else - in ITS L(t - 3) (I_2t-5): the slot's tile t - 4 was last read in M(t - 4) (I_2t-7 / I_2t-6).  The
+//       counted wait at the end of M(t - 1) (group 0, I_2t-1) / M(t - 2) (group 1, I_2t-2) covers it - three intervals of
+//       flight for both - and the first read is L(t) (I_2t / I_2t+1).
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void sg_bar() {
     asm volatile("" ::: "memory");
@@ -545,21 +552,40 @@ __device__ __forceinline__ void sg_bar() {
 }
 __device__ __forceinline__ void sg_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-#ifndef RK_SG_TRACE
-#define RK_SG_TRACE 0
-#endif
 // timing probes (wrong results): RK_PH_PROBE bit 0: no DMA, 1: no matrix-core instructions, 2: no split / LDS store of the K
-// tile, 3: no stagger, 4: no K-tile loads
+// tile, 3: no stagger, 4: no K-tile loads, 5: K-tile loads of the same eight tiles over and over (cache hits)
 #ifndef RK_PH_PROBE
 #define RK_PH_PROBE 0
 #endif
 #ifndef RK_SG_FILL
-#define RK_SG_FILL 2  // vector instructions the scheduler may place behind each matrix-core instruction of a phase M
+#define RK_SG_FILL 1  // vector instructions the scheduler may place behind each matrix-core instruction of a phase M
 #endif
-#if RK_SG_TRACE  // tuning builds only: cycle stamps after every barrier of 16 steps of one workgroup (tools/ab_symgemm.py --trace)
-__device__ unsigned long long sg_trace_buf[512];
-constexpr int SG_TRACE_BLOCK = 300, SG_TRACE_Q0 = 100;
-#endif
+
+struct SgStageT { float a[8]; };   // transposed phase: 8 rows j of one column i
+struct SgStageD { sg_u4 d[2]; };   // direct phase: 4 columns j of two rows i
+struct SgPkT { sg_u4 o[2]; };      // the split pieces of a thread's part of a K tile, as they go to LDS
+struct SgPkD { sg_u2 o[2][2]; };
+// the pieces count as written HERE (the compiler would otherwise sink the split to its use, behind the next barrier)
+__device__ __forceinline__ void sg_pin(SgPkT& pk) { asm volatile("" : "+v"(pk.o[0]), "+v"(pk.o[1])); }
+__device__ __forceinline__ void sg_pin(SgPkD& pk) {
+    asm volatile("" : "+v"(pk.o[0][0]), "+v"(pk.o[0][1]), "+v"(pk.o[1][0]), "+v"(pk.o[1][1]));
+}
+struct SgWaitT {  // vmcnt(N) naming a register set: the set counts as written here, not at its asm load
+    template <int N> static __device__ __forceinline__ void at(SgStageT& st) {
+        asm volatile("s_waitcnt vmcnt(%8)"
+                     : "+v"(st.a[0]), "+v"(st.a[1]), "+v"(st.a[2]), "+v"(st.a[3]), "+v"(st.a[4]), "+v"(st.a[5]),
+                       "+v"(st.a[6]), "+v"(st.a[7])
+                     : "n"(N)
+                     : "memory");
+    }
+    static constexpr int NA = 8;  // loads per K tile and thread
+};
+struct SgWaitD {
+    template <int N> static __device__ __forceinline__ void at(SgStageD& st) {
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(st.d[0]), "+v"(st.d[1]) : "n"(N) : "memory");
+    }
+    static constexpr int NA = 2;
+};
 
 template <int NCB>
 __global__ void __launch_bounds__(SG_THREADS, 2)
@@ -569,7 +595,7 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
     using F = SgF16;
     constexpr int NS = 2;
     constexpr int TN = 32 * NCB;
-    constexpr int HC = NCB / 2;                 // 16-column blocks per wave and phase M
+    constexpr int QC = NCB / 4;                 // 16-column blocks per wave and quarter of a phase M
     constexpr int W = SgLayout::W;
     constexpr int ABYTES = SG_TM * SG_ROWB;     // one piece of the K tile: 8 KiB
     constexpr int BBYTES = TN * SG_ROWB;        // one piece of the V tile
@@ -577,7 +603,7 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
     constexpr int NBQ = BTILE / 16 / SG_THREADS;  // DMAs per wave and tile: wave w copies bytes [w NBQ KiB, (w + 1) NBQ KiB)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // (the only LDS object of the kernel)
     unsigned char* AL = smem;                       // [2][NS][ABYTES]
-    unsigned char* BL = smem + 2 * NS * ABYTES;     // [3][BTILE]
+    unsigned char* BL = smem + 2 * NS * ABYTES;     // [4][BTILE]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -618,41 +644,31 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
             }
     };
 
-    // ---- V tiles: LDS-DMA, one 1 KiB piece per call ------------------------------------------------------------------
+    // ---- V tiles: LDS-DMA, NBQ pieces of 1 KiB per wave and tile -----------------------------------------------------
     const unsigned char* bsrc0 = img + (ct * NS) * (int64_t)BBYTES + wave * (NBQ * 1024) + lane * 16;
-    auto dma_piece = [&](int64_t jstep, int slot, auto piece_tag) {
-        constexpr int piece = decltype(piece_tag)::value;
-        if constexpr (piece < NBQ && !(RK_PH_PROBE & 1)) {
+    auto dma_b = [&](int64_t jstep, int slot) {
+        if constexpr (!(RK_PH_PROBE & 1)) {
             const unsigned char* src = bsrc0 + jstep * nct * (int64_t)BTILE;
             auto* dst = (__attribute__((address_space(3))) void*)(BL + slot * BTILE + wave * (NBQ * 1024));
-            __builtin_amdgcn_global_load_lds(src, dst, 16, piece * 1024, 0);
+            __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+            if constexpr (NBQ > 1) __builtin_amdgcn_global_load_lds(src, dst, 16, 1024, 0);
+            if constexpr (NBQ > 2) __builtin_amdgcn_global_load_lds(src, dst, 16, 2048, 0);
+            if constexpr (NBQ > 3) __builtin_amdgcn_global_load_lds(src, dst, 16, 3072, 0);
         }
     };
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-    using P2 = std::integral_constant<int, 2>;
-    using P3 = std::integral_constant<int, 3>;
-    // pieces [0, NBQ / 2) go out in phase M0, the rest in M1
-    auto dma_first = [&](int64_t jstep, int slot) {
-        dma_piece(jstep, slot, P0{});
-        if constexpr (NBQ >= 4) dma_piece(jstep, slot, P1{});
-    };
-    auto dma_second = [&](int64_t jstep, int slot) {
-        if constexpr (NBQ >= 4) {
-            dma_piece(jstep, slot, P2{});
-            dma_piece(jstep, slot, P3{});
-        } else if constexpr (NBQ >= 2) {
-            dma_piece(jstep, slot, P1{});
-        }
-    };
-    constexpr int NB1 = NBQ >= 4 ? 2 : 1;  // DMAs of dma_first
     // ---- K tiles: asm loads, counted waits ---------------------------------------------------------------------------
-    struct StageT { float a[8]; };   // transposed phase: 8 rows j of one column i
-    struct StageD { sg_u4 d[2]; };   // direct phase: 4 columns j of two rows i
-    struct PkT { sg_u4 o[NS]; };     // the split pieces of a thread's part of a K tile, as they go to LDS
-    struct PkD { sg_u2 o[2][NS]; };
+    using StageT = SgStageT;
+    using StageD = SgStageD;
+    // a group stages the 64 rows of the K tile that its own waves read (rows 64 grp .. + 64): no LDS traffic between the
+    // groups for the K tiles.  tg = thread in the group.  Transposed tiles: column ti of the strip, 8-row chunk tch;
+    // direct tiles: rows td and td + 32 of the group's 64, columns 4 (tg % 8) .. + 4
+    const int tg = tid & 255;
+    const int ti = grp * 64 + (tg & 63), tch = tg >> 6;
+    const int td = grp * 64 + (tg >> 3);
+    using PkT = SgPkT;
+    using PkD = SgPkD;
     auto load_t = [&](int64_t q, StageT& st) {
-        const float* p0 = Kp + (L.row_offset(tb) + q * SG_KT + (tid >> 7) * 8) * W + ioff + (tid & 127);
+        const float* p0 = Kp + (L.row_offset(tb) + q * SG_KT + tch * 8) * W + ioff + ti;
         const float* p1 = p0 + 4 * W;
         asm volatile(
             "global_load_dword %0, %8, off nt\n\t"
@@ -669,33 +685,11 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
             : "memory");
     };
     auto jstep_t = [&](int64_t q) { return q; };
-    // the queue behind K tile q + 1 when phase L0 of step q waits for it: [V tile q, landed] [K tile q + 2] [V tile q + 1]
-    // [K tile q + 3]: NBQ + 2 NA may stay in flight (in step 0 the V tile q + 2 is not yet in the queue: the same count)
-    auto wait_t = [&](StageT& st) {
-        asm volatile("s_waitcnt vmcnt(%8)"
-                     : "+v"(st.a[0]), "+v"(st.a[1]), "+v"(st.a[2]), "+v"(st.a[3]), "+v"(st.a[4]), "+v"(st.a[5]),
-                       "+v"(st.a[6]), "+v"(st.a[7])
-                     : "n"(16 + NBQ)
-                     : "memory");
-    };
-    auto waitb_t = [&]() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(8 + NB1) : "memory"); };
-    auto drain_t2 = [&](StageT& x, StageT& y) {  // everything has landed; the sets stay allocated until here
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(x.a[0]), "+v"(x.a[1]), "+v"(x.a[2]), "+v"(x.a[3]), "+v"(x.a[4]), "+v"(x.a[5]), "+v"(x.a[6]),
-                       "+v"(x.a[7]), "+v"(y.a[0]), "+v"(y.a[1]), "+v"(y.a[2]), "+v"(y.a[3]), "+v"(y.a[4]), "+v"(y.a[5]),
-                       "+v"(y.a[6]), "+v"(y.a[7])
-                     :
-                     : "memory");
-    };
-    auto drain_t = [&](StageT& x, StageT& y, StageT& z, StageT& w) {
-        drain_t2(x, y);
-        drain_t2(z, w);
-    };
     auto load_d = [&](int64_t q, StageD& st) {
         const int64_t t = t_min + q / (W / SG_KT);
         const int kk = (int)(q % (W / SG_KT)) * SG_KT;
         const float* base = Kp + L.row_offset(t) * W + kk + (tid & 7) * 4;
-        int64_t r0 = i0 + (tid >> 3), r1 = r0 + 64;
+        int64_t r0 = i0 + td, r1 = r0 + 32;
         r0 = r0 < L.n ? r0 : L.n - 1;  // (rows past n: finite stand-ins, never stored)
         r1 = r1 < L.n ? r1 : L.n - 1;
         const float* p0 = base + r0 * W;
@@ -711,16 +705,6 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
         const int64_t t = t_min + q / (W / SG_KT);
         return (L.first + t * L.stride) * (W / SG_KT) + q % (W / SG_KT);
     };
-    auto wait_d = [&](StageD& st) {
-        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(st.d[0]), "+v"(st.d[1]) : "n"(4 + NBQ) : "memory");
-    };
-    auto waitb_d = [&]() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 + NB1) : "memory"); };
-    auto drain_d = [&](StageD& x, StageD& y, StageD& z, StageD& w) {
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(x.d[0]), "+v"(x.d[1]), "+v"(y.d[0]), "+v"(y.d[1]), "+v"(z.d[0]), "+v"(z.d[1]), "+v"(w.d[0]), "+v"(w.d[1])
-                     :
-                     : "memory");
-    };
     // ---- registers -> pieces (scale, split), pieces -> LDS (operand layout) -------------------------------------------
     auto split_t = [&](const StageT& st) {
         unsigned pk[4][NS];
@@ -731,7 +715,7 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
         for (int p = 0; p < NS; ++p) { out.o[p].x = pk[0][p]; out.o[p].y = pk[1][p]; out.o[p].z = pk[2][p]; out.o[p].w = pk[3][p]; }
         return out;
     };
-    const int st_off_t = (tid & 127) * SG_ROWB + (sg_swz(tid & 127, tid >> 7) << 4);
+    const int st_off_t = ti * SG_ROWB + (sg_swz(ti, tch) << 4);
     auto store_t = [&](int buf, const PkT& pk) {
         unsigned char* dst = AL + buf * NS * ABYTES + st_off_t;
 #pragma unroll
@@ -749,18 +733,18 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
         }
         return out;
     };
-    const int st_off_d = (tid >> 3) * SG_ROWB + (sg_swz(tid >> 3, (tid & 7) >> 1) << 4) + (tid & 1) * 8;  // (+ 64 rows: same swizzle)
+    const int st_off_d = td * SG_ROWB + (sg_swz(td, (tid & 7) >> 1) << 4) + (tid & 1) * 8;  // (+ 32 rows: same swizzle)
     auto store_d = [&](int buf, const PkD& pk) {
         unsigned char* dst = AL + buf * NS * ABYTES + st_off_d;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int p = 0; p < NS; ++p) *reinterpret_cast<sg_u2*>(dst + u * 64 * SG_ROWB + p * ABYTES) = pk.o[u][p];
+            for (int p = 0; p < NS; ++p) *reinterpret_cast<sg_u2*>(dst + u * 32 * SG_ROWB + p * ABYTES) = pk.o[u][p];
     };
     // ---- operand reads and matrix-core work --------------------------------------------------------------------------
     const int a_off = (wr * 16 * SG_RB + lr) * SG_ROWB + (sg_swz(lr, lq) << 4);
     const int b_off = (wc * (TN / 2) + lr) * SG_ROWB + (sg_swz(lr, lq) << 4);
-    sg_u4 af[SG_RB][NS], bf[HC][NS];
+    sg_u4 af[SG_RB][NS], bfa[QC][NS], bfb[QC][NS];
     auto read_a = [&](int buf) {
         const unsigned char* al = AL + buf * NS * ABYTES + a_off;
 #pragma unroll
@@ -768,18 +752,17 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
 #pragma unroll
             for (int p = 0; p < NS; ++p) af[r][p] = *reinterpret_cast<const sg_u4*>(al + r * 16 * SG_ROWB + p * ABYTES);
     };
-    auto read_b = [&](int slot, int half) {
-        const unsigned char* bl = BL + slot * BTILE + b_off + half * HC * 16 * SG_ROWB;
+    auto read_bq = [&](int slot, int quarter, sg_u4 (&bf)[QC][NS]) {
+        const unsigned char* bl = BL + slot * BTILE + b_off + quarter * QC * 16 * SG_ROWB;
 #pragma unroll
-        for (int c = 0; c < HC; ++c)
+        for (int c = 0; c < QC; ++c)
 #pragma unroll
             for (int p = 0; p < NS; ++p) bf[c][p] = *reinterpret_cast<const sg_u4*>(bl + c * 16 * SG_ROWB + p * BBYTES);
     };
-    auto mma = [&](auto half_tag) {
-        constexpr int half = decltype(half_tag)::value;
+    auto mma_q = [&](int quarter, const sg_u4 (&bf)[QC][NS]) {
         if constexpr (RK_PH_PROBE & 2) {  // (keep the operand reads alive)
 #pragma unroll
-            for (int c = 0; c < HC; ++c)
+            for (int c = 0; c < QC; ++c)
 #pragma unroll
                 for (int r = 0; r < SG_RB; ++r)
                     asm volatile("" : : "v"(af[r][0]), "v"(af[r][1]), "v"(bf[c][0]), "v"(bf[c][1]));
@@ -787,148 +770,122 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
         }
         // small terms first (the order of symgemm_kernel per accumulator): m.h, h.m, then h.h
 #pragma unroll
-        for (int c = 0; c < HC; ++c)
+        for (int c = 0; c < QC; ++c)
 #pragma unroll
-            for (int r = 0; r < SG_RB; ++r) acc[r][half * HC + c] = F::mfma(af[r][0], bf[c][1], acc[r][half * HC + c]);
+            for (int r = 0; r < SG_RB; ++r) acc[r][quarter * QC + c] = F::mfma(af[r][0], bf[c][1], acc[r][quarter * QC + c]);
 #pragma unroll
-        for (int c = 0; c < HC; ++c)
+        for (int c = 0; c < QC; ++c)
 #pragma unroll
-            for (int r = 0; r < SG_RB; ++r) acc[r][half * HC + c] = F::mfma(af[r][1], bf[c][0], acc[r][half * HC + c]);
+            for (int r = 0; r < SG_RB; ++r) acc[r][quarter * QC + c] = F::mfma(af[r][1], bf[c][0], acc[r][quarter * QC + c]);
 #pragma unroll
-        for (int c = 0; c < HC; ++c)
+        for (int c = 0; c < QC; ++c)
 #pragma unroll
-            for (int r = 0; r < SG_RB; ++r) acc[r][half * HC + c] = F::mfma(af[r][0], bf[c][0], acc[r][half * HC + c]);
+            for (int r = 0; r < SG_RB; ++r) acc[r][quarter * QC + c] = F::mfma(af[r][0], bf[c][0], acc[r][quarter * QC + c]);
     };
-    // the order of a phase M for the scheduler: one matrix-core instruction, two vector instructions (the split of the
-    // next K tile: the matrix-core instruction holds the issue port for 8 of its 16 cycles), a DMA after every eighth
-    auto interleave = [&]() {
+    // the order of a quarter for the scheduler: matrix-core instructions with RK_SG_FILL vector instructions (the split
+    // of a K tile) behind each - a matrix-core instruction holds the issue port for 8 of its 16 cycles
+    auto quarter_order = [&](int first, int last) {
 #pragma unroll
-        for (int g = 0; g < 3 * HC * SG_RB; ++g) {
+        for (int g = first; g < last; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, RK_SG_FILL, 0);
-            if (g % 8 == 7 && g / 8 < NB1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
     };
-    using H0 = std::integral_constant<int, 0>;
-    using H1 = std::integral_constant<int, 1>;
 
-#if RK_SG_TRACE
-    unsigned long long* tr = reinterpret_cast<unsigned long long*>(smem + 2 * NS * ABYTES + 3 * BTILE);
-    const bool tracing = blockIdx.x == SG_TRACE_BLOCK && lane == 0 && (wave & 3) == 0;
-    bool trace_phase = false;
-    auto stamp = [&](int64_t q, int point) {
-        if (tracing && trace_phase && q >= SG_TRACE_Q0 && q < SG_TRACE_Q0 + 16)
-            tr[((q - SG_TRACE_Q0) * 9 + point) * 2 + grp] = clock64();
-    };
-#else
-    auto stamp = [&](int64_t, int) {};
-#endif
     if (grp == 1 && !(RK_PH_PROBE & 8)) sg_bar();  // the second group runs one barrier behind the first from here on
 
-    auto run_phase = [&](auto load, auto jstep, auto wait, auto waitb, auto drain, auto split, auto store, auto& s0,
-                         auto& s1, auto& s2, auto& s3, int64_t nst) {
+    auto run_phase = [&](auto load, auto jstep, auto waiter, auto split, auto store, auto& s0, auto& s1, auto& s2, auto& s3,
+                         int64_t nst) {
         if (nst <= 0) return;
+        using Wt = decltype(waiter);
+        constexpr int NA = Wt::NA;
         auto at = [&](int64_t q) { return q < nst ? q : nst - 1; };  // (past the end: the last step again, unused)
-        // K tile t lives in register set t % 4 and is loaded three steps before its step; V tile t in ring slot t % 3
+        // K tile t lives in register set t % 4, V tile t in ring slot t % 4
+        dma_b(jstep(0), 0);
+        dma_b(jstep(at(1)), 1);
+        if (grp == 1) dma_b(jstep(at(2)), 2);
         load(0, s0);
-        dma_first(jstep(0), 0);
-        dma_second(jstep(0), 0);
         load(at(1), s1);
-        dma_first(jstep(at(1)), 1);
-        dma_second(jstep(at(1)), 1);
         load(at(2), s2);
-        wait(s0);   // K tile 0 and V tile 0 (the queue behind them: K tile 1, V tile 1, K tile 2)
+        load(at(3), s3);
+        Wt::template at<2 * NA>(s0);
         store(0, split(s0));
+        Wt::template at<2 * NA>(s1);         // V tiles 0, 1 and K tiles 0, 1 (K tiles 2, 3 stay in flight)
+        auto pk = split(s1);                 // (goes to LDS in L(0))
+        Wt::template at<0>(s2);
+        Wt::template at<0>(s3);
         sg_lgkm0();
         sg_bar();
         sg_bar();
-        int slot = 0;  // ring slot of the V tile of the current step
-        auto step = [&](int64_t q, int buf, auto& st_load, auto& st_store) {
-            const int slot2 = slot >= 1 ? slot - 1 : 2;   // (slot + 2) % 3
-            const int64_t j2 = jstep(at(q + 2));
-            // L0: operand reads, the K tile two steps ahead; the K tile of the next step has landed
+        // one step: tile q (K buffer q % 2, V slot q % 4); st_load <- K tile q + 4 (the set of tile q), st_split = K tile
+        // q + 2, st_next = K tile q + 3 (certified by this step's wait, split in the next step)
+        auto step = [&](int64_t q, auto qtag, auto& st_load, auto& st_split, auto& st_next) {
+            constexpr int qm = decltype(qtag)::value;  // q % 4
+            constexpr int buf = qm & 1, slot = qm;
+            const int slot2 = (qm + 2 + grp) & 3;   // the V tile this wave's DMAs fetch: q + 2 (group 0), q + 3 (group 1)
+            // ---- L(q): issue only
+            if constexpr (!(RK_PH_PROBE & 4)) store(buf ^ 1, pk);     // K tile q + 1 (own rows)
             read_a(buf);
-            read_b(slot, 0);
-            if constexpr (!(RK_PH_PROBE & 16)) load(at(q + 3), st_load);
-            wait(st_store);
+            read_bq(slot, 0, bfa);
+            read_bq(slot, 1, bfb);
+            dma_b(jstep(at(q + 2 + grp)), slot2);
+            if constexpr (!(RK_PH_PROBE & 16)) load((RK_PH_PROBE & 32) ? (q & 7) : at(q + 4), st_load);  // (bit 5: cached tiles)
             sg_bar();
-            stamp(q, 0);
-            // M0: 24 matrix-core instructions; between them the split of the next K tile and half the DMAs of the V tile
-            // two steps ahead
+            // ---- M(q): quarter 0 | reads of quarter 2 | quarter 1 | part of quarter 2 | reads of quarter 3 | rest
             __builtin_amdgcn_s_setprio(1);
-#if RK_SG_TRACE
-            sg_lgkm0();
-            stamp(q, 1);
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-            mma(H0{});
-            auto pk = split(st_store);
+            mma_q(0, bfa);
+            pk = split(st_split);
             if constexpr (RK_PH_PROBE & 4) pk = decltype(pk){};
-            dma_first(j2, slot2);
-            interleave();
+            read_bq(slot, 2, bfa);
+            mma_q(1, bfb);
+            mma_q(2, bfa);
+            read_bq(slot, 3, bfb);
+            mma_q(3, bfb);
+            // the order for the scheduler (the reads of quarter 3 a few instructions into quarter 2: the wait in front of
+            // quarter 2 then covers quarter 2's own reads only)
+            constexpr int QM = 3 * QC * SG_RB;  // matrix-core instructions of a quarter
+            quarter_order(0, QM);
+            __builtin_amdgcn_sched_group_barrier(0x100, QC * NS, 0);
+            quarter_order(0, QM);
+            quarter_order(0, QM / 3);
+            __builtin_amdgcn_sched_group_barrier(0x100, QC * NS, 0);
+            quarter_order(QM / 3, QM);
+            quarter_order(0, QM);
+            sg_pin(pk);
             __builtin_amdgcn_s_setprio(0);
-#if RK_SG_TRACE
-            __builtin_amdgcn_sched_barrier(0);
-            stamp(q, 2);
-#endif
-            sg_bar();
-            stamp(q, 3);
-            // L1: operand reads, the next K tile to LDS; the V tile of the next step has landed
-            read_b(slot, 1);
-            if constexpr (!(RK_PH_PROBE & 4)) store(buf ^ 1, pk);
-            waitb();
-            sg_lgkm0();
-#if RK_SG_TRACE
-            stamp(q, 4);
-#endif
-            sg_bar();
-            stamp(q, 5);
-            __builtin_amdgcn_s_setprio(1);
-#if RK_SG_TRACE
-            sg_lgkm0();
-            stamp(q, 6);
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-            mma(H1{});
-            dma_second(j2, slot2);
-            interleave();
-            __builtin_amdgcn_s_setprio(0);
-#if RK_SG_TRACE
-            __builtin_amdgcn_sched_barrier(0);
-            stamp(q, 7);
-#endif
             if (((int)q & fold_mask) == fold_mask) fold();
+            // the waits of the step, behind its matrix-core work: K tile q + 3 and the DMAs issued in L(q - 1) have landed
+            // (what L(q) issued stays in flight), this wave's LDS stores of L(q) are done
+            __builtin_amdgcn_sched_barrier(0);
+            Wt::template at<NA + NBQ>(st_next);
+            sg_lgkm0();
             sg_bar();
-            stamp(q, 8);
-            slot = slot == 2 ? 0 : slot + 1;
         };
+        using Q0 = std::integral_constant<int, 0>;
+        using Q1 = std::integral_constant<int, 1>;
+        using Q2 = std::integral_constant<int, 2>;
+        using Q3 = std::integral_constant<int, 3>;
         for (int64_t q = 0; q < nst; q += 4) {
-            step(q, 0, s3, s1);
-            if (q + 1 < nst) step(q + 1, 1, s0, s2);
-            if (q + 2 < nst) step(q + 2, 0, s1, s3);
-            if (q + 3 < nst) step(q + 3, 1, s2, s0);
+            step(q, Q0{}, s0, s2, s3);
+            if (q + 1 < nst) step(q + 1, Q1{}, s1, s3, s0);
+            if (q + 2 < nst) step(q + 2, Q2{}, s2, s0, s1);
+            if (q + 3 < nst) step(q + 3, Q3{}, s3, s1, s2);
         }
-        drain(s0, s1, s2, s3);  // the loads past the end: the next phase counts from zero, no register is reused under a load
+        // the loads past the end: the next phase counts from zero, no register is reused under a load
+        Wt::template at<0>(s0);
+        Wt::template at<0>(s1);
+        Wt::template at<0>(s2);
+        Wt::template at<0>(s3);
     };
     {
         StageT s0, s1, s2, s3;
-        run_phase(load_t, jstep_t, wait_t, waitb_t, drain_t, split_t, store_t, s0, s1, s2, s3, nT);
+        run_phase(load_t, jstep_t, SgWaitT{}, split_t, store_t, s0, s1, s2, s3, nT);
     }
     {
         StageD s0, s1, s2, s3;
-#if RK_SG_TRACE
-        trace_phase = true;
-#endif
-        run_phase(load_d, jstep_d, wait_d, waitb_d, drain_d, split_d, store_d, s0, s1, s2, s3, nD);
+        run_phase(load_d, jstep_d, SgWaitD{}, split_d, store_d, s0, s1, s2, s3, nD);
     }
     if (grp == 0 && !(RK_PH_PROBE & 8)) sg_bar();
-#if RK_SG_TRACE
-    if (blockIdx.x == SG_TRACE_BLOCK) {
-        sg_lgkm0();
-        sg_bar();
-        if (tid < 288) sg_trace_buf[tid] = tr[tid];
-    }
-#endif
 
     const int64_t kpad = nct * TN;
 #pragma unroll
@@ -1190,9 +1147,9 @@ static bool sg_use_bf16x3() {
     const char* e = getenv("RK_SYMGEMM_SPLIT");
     return e != nullptr && (e[0] == 'b' || e[0] == '3');
 }
-static bool sg_use_phases() {  // RK_SYMGEMM_IMPL=ph: symgemm_ph_kernel (two wave groups half a step apart)
+static bool sg_use_phases() {  // symgemm_ph_kernel (two wave groups half a step apart) unless RK_SYMGEMM_IMPL=lockstep
     const char* e = getenv("RK_SYMGEMM_IMPL");
-    return e != nullptr && e[0] == 'p';
+    return e == nullptr || e[0] != 'l';
 }
 static int sg_tn(int64_t k) { return k <= 128 ? 128 : 256; }
 static size_t sg_image_bytes(int64_t n, int64_t k, int ns) {
@@ -1285,7 +1242,7 @@ extern "C" int rk_symm_gemm(const void* Kp, int64_t n, int64_t strip_first, int6
     } while (0)
 #define RK_SGPH(NCBV)                                                                                            \
     do {                                                                                                         \
-        constexpr size_t smem = 2 * 2 * SG_TM * SG_ROWB + 3 * 2 * 32 * NCBV * SG_ROWB + (RK_SG_TRACE ? 4096 : 0);   \
+        constexpr size_t smem = 2 * 2 * SG_TM * SG_ROWB + 4 * 2 * 32 * NCBV * SG_ROWB;                           \
         static std::atomic<unsigned long long> attr_devs{0};                                                     \
         int dev_ = 0;                                                                                            \
         (void)hipGetDevice(&dev_);                                                                               \
@@ -1316,12 +1273,6 @@ extern "C" int rk_symm_gemm(const void* Kp, int64_t n, int64_t strip_first, int6
 #undef RK_SGPH
     return launch_status("rk_symm_gemm");
 }
-
-#if RK_SG_TRACE
-extern "C" int rk_debug_symgemm_trace(unsigned long long* out) {  // 288 stamps: [step][point][group]
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sg_trace_buf), 288 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
-}
-#endif
 
 // ---- the fused evaluate-and-multiply product (matrix-free operators) -------------------------------------------------
 static size_t kg_x_bytes(int64_t n) {  // |x'|^2 of the padded points + their split images
