@@ -189,6 +189,15 @@ size_t rk_symm_gemm_ws_bytes(int64_t n, int64_t k);
 int rk_symm_gemm(const void* Kp, int64_t n, int64_t strip_first, int64_t strip_stride, double kmax,
                  const void* V, int64_t k, int64_t ldv, double alpha, void* Y, int64_t ldy, void* ws,
                  size_t ws_bytes, void* stream);
+/* The same product for a V on the FLOAT16 GRID - every entry, times the power of two the kernel scales its column by,
+ * exactly a float16 number; true of any matrix that was rounded to float16 once, such as a Gaussian test matrix the
+ * caller draws itself (the sketch Omega of rlaopt/sketches/gauss.py:46-52 is random either way: rounding its entries to
+ * 11 significant bits leaves it a Gaussian sketch).  V then has ONE piece: two exact products per pair instead of three
+ * and half the bytes of V tiles through each CU - the two things rk_symm_gemm's time is made of.  Entries off the grid are
+ * ROUNDED to it (the result is K round(V)); same arguments, same workspace, same reproducibility. */
+int rk_symm_gemm_rhs16(const void* Kp, int64_t n, int64_t strip_first, int64_t strip_stride, double kmax,
+                       const void* V, int64_t k, int64_t ldv, double alpha, void* Y, int64_t ldy, void* ws,
+                       size_t ws_bytes, void* stream);
 
 /* The same wide product for an operator that stores NOTHING (matrix-free): Y (n1 x k) = alpha * scale *
  * K(X1, X2) V for up to 1024 columns - Y = A @ Omega of rlaopt/preconditioners/nystrom.py:79 as the reference itself

@@ -190,7 +190,7 @@ __global__ void sg_scale_kernel(unsigned* __restrict__ info, int64_t kpad, int e
 // ---- prologue 2: the split image of V -----------------------------------------------------------------
 // image[step = j / 32][column tile][piece][column in tile][32 halves, chunks swizzled]; rows >= n and
 // columns >= k are zero.  One thread per (column, 8-row chunk).
-template <typename F>
+template <typename F, int NSB = F::NS>  // NSB < F::NS: only the leading pieces are kept (V on the grid of the first piece)
 __global__ void __launch_bounds__(256)
 sg_split_rhs_kernel(const float* __restrict__ V, int64_t n, int64_t npad, int64_t k, int64_t kpad, int64_t ldv,
                     int tn, const unsigned* __restrict__ info, unsigned char* __restrict__ img) {
@@ -213,9 +213,9 @@ sg_split_rhs_kernel(const float* __restrict__ V, int64_t n, int64_t npad, int64_
     const int64_t ct = col / tn;
     const int cl = (int)(col % tn);
     const int64_t nct = kpad / tn;
-    unsigned char* base = img + ((step * nct + ct) * F::NS) * (int64_t)tn * SG_ROWB + cl * SG_ROWB + (sg_swz(cl, q) << 4);
+    unsigned char* base = img + ((step * nct + ct) * NSB) * (int64_t)tn * SG_ROWB + cl * SG_ROWB + (sg_swz(cl, q) << 4);
 #pragma unroll
-    for (int p = 0; p < F::NS; ++p) {
+    for (int p = 0; p < NSB; ++p) {
         sg_u4 o;
         o.x = pk[0][p]; o.y = pk[1][p]; o.z = pk[2][p]; o.w = pk[3][p];
         *reinterpret_cast<sg_u4*>(base + (int64_t)p * tn * SG_ROWB) = o;
@@ -587,7 +587,7 @@ struct SgWaitD {
     static constexpr int NA = 2;
 };
 
-template <int NCB>
+template <int NCB, int NSB>  // NSB: pieces of V (2, or 1 for a V on the float16 grid: two exact products per pair, half the V bytes)
 __global__ void __launch_bounds__(SG_THREADS, 2)
 symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __restrict__ img, int64_t nct,
                   float sa, const unsigned* __restrict__ info, int64_t k, float* __restrict__ Y, int64_t ldy,
@@ -599,7 +599,7 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
     constexpr int W = SgLayout::W;
     constexpr int ABYTES = SG_TM * SG_ROWB;     // one piece of the K tile: 8 KiB
     constexpr int BBYTES = TN * SG_ROWB;        // one piece of the V tile
-    constexpr int BTILE = NS * BBYTES;          // a V tile: 32 KiB (TN = 256)
+    constexpr int BTILE = NSB * BBYTES;         // a V tile: 32 KiB (TN = 256, two pieces)
     constexpr int NBQ = BTILE / 16 / SG_THREADS;  // DMAs per wave and tile: wave w copies bytes [w NBQ KiB, (w + 1) NBQ KiB)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // (the only LDS object of the kernel)
     unsigned char* AL = smem;                       // [2][NS][ABYTES]
@@ -645,7 +645,7 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
     };
 
     // ---- V tiles: LDS-DMA, NBQ pieces of 1 KiB per wave and tile -----------------------------------------------------
-    const unsigned char* bsrc0 = img + (ct * NS) * (int64_t)BBYTES + wave * (NBQ * 1024) + lane * 16;
+    const unsigned char* bsrc0 = img + (ct * NSB) * (int64_t)BBYTES + wave * (NBQ * 1024) + lane * 16;
     auto dma_b = [&](int64_t jstep, int slot) {
         if constexpr (!(RK_PH_PROBE & 1)) {
             const unsigned char* src = bsrc0 + jstep * nct * (int64_t)BTILE;
@@ -744,7 +744,7 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
     // ---- operand reads and matrix-core work --------------------------------------------------------------------------
     const int a_off = (wr * 16 * SG_RB + lr) * SG_ROWB + (sg_swz(lr, lq) << 4);
     const int b_off = (wc * (TN / 2) + lr) * SG_ROWB + (sg_swz(lr, lq) << 4);
-    sg_u4 af[SG_RB][NS], bfa[QC][NS], bfb[QC][NS];
+    sg_u4 af[SG_RB][NS], bfa[QC][NSB], bfb[QC][NSB];
     auto read_a = [&](int buf) {
         const unsigned char* al = AL + buf * NS * ABYTES + a_off;
 #pragma unroll
@@ -752,27 +752,30 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
 #pragma unroll
             for (int p = 0; p < NS; ++p) af[r][p] = *reinterpret_cast<const sg_u4*>(al + r * 16 * SG_ROWB + p * ABYTES);
     };
-    auto read_bq = [&](int slot, int quarter, sg_u4 (&bf)[QC][NS]) {
+    auto read_bq = [&](int slot, int quarter, sg_u4 (&bf)[QC][NSB]) {
         const unsigned char* bl = BL + slot * BTILE + b_off + quarter * QC * 16 * SG_ROWB;
 #pragma unroll
         for (int c = 0; c < QC; ++c)
 #pragma unroll
-            for (int p = 0; p < NS; ++p) bf[c][p] = *reinterpret_cast<const sg_u4*>(bl + c * 16 * SG_ROWB + p * BBYTES);
+            for (int p = 0; p < NSB; ++p) bf[c][p] = *reinterpret_cast<const sg_u4*>(bl + c * 16 * SG_ROWB + p * BBYTES);
     };
-    auto mma_q = [&](int quarter, const sg_u4 (&bf)[QC][NS]) {
+    auto mma_q = [&](int quarter, const sg_u4 (&bf)[QC][NSB]) {
         if constexpr (RK_PH_PROBE & 2) {  // (keep the operand reads alive)
 #pragma unroll
             for (int c = 0; c < QC; ++c)
 #pragma unroll
                 for (int r = 0; r < SG_RB; ++r)
-                    asm volatile("" : : "v"(af[r][0]), "v"(af[r][1]), "v"(bf[c][0]), "v"(bf[c][1]));
+                    asm volatile("" : : "v"(af[r][0]), "v"(af[r][1]), "v"(bf[c][0]), "v"(bf[c][NSB - 1]));
             return;
         }
-        // small terms first (the order of symgemm_kernel per accumulator): m.h, h.m, then h.h
+        // small terms first (the order of symgemm_kernel per accumulator): h.m (two pieces of V only), m.h, then h.h
+        if constexpr (NSB == 2) {
 #pragma unroll
-        for (int c = 0; c < QC; ++c)
+            for (int c = 0; c < QC; ++c)
 #pragma unroll
-            for (int r = 0; r < SG_RB; ++r) acc[r][quarter * QC + c] = F::mfma(af[r][0], bf[c][1], acc[r][quarter * QC + c]);
+                for (int r = 0; r < SG_RB; ++r)
+                    acc[r][quarter * QC + c] = F::mfma(af[r][0], bf[c][NSB - 1], acc[r][quarter * QC + c]);
+        }
 #pragma unroll
         for (int c = 0; c < QC; ++c)
 #pragma unroll
@@ -843,13 +846,14 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
             mma_q(3, bfb);
             // the order for the scheduler (the reads of quarter 3 a few instructions into quarter 2: the wait in front of
             // quarter 2 then covers quarter 2's own reads only)
-            constexpr int QM = 3 * QC * SG_RB;  // matrix-core instructions of a quarter
+            constexpr int QM = (NSB + 1) * QC * SG_RB;  // matrix-core instructions of a quarter
+            constexpr int QH = QM / (NSB + 1);          // (the first of its NSB + 1 passes)
             quarter_order(0, QM);
-            __builtin_amdgcn_sched_group_barrier(0x100, QC * NS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, QC * NSB, 0);
             quarter_order(0, QM);
-            quarter_order(0, QM / 3);
-            __builtin_amdgcn_sched_group_barrier(0x100, QC * NS, 0);
-            quarter_order(QM / 3, QM);
+            quarter_order(0, QH);
+            __builtin_amdgcn_sched_group_barrier(0x100, QC * NSB, 0);
+            quarter_order(QH, QM);
             quarter_order(0, QM);
             sg_pin(pk);
             __builtin_amdgcn_s_setprio(0);
@@ -1167,9 +1171,9 @@ extern "C" size_t rk_symm_gemm_ws_bytes(int64_t n, int64_t k) {
     return SG_INFO_BYTES + sg_image_bytes(n, k, sg_use_bf16x3() ? 3 : 2);
 }
 
-extern "C" int rk_symm_gemm(const void* Kp, int64_t n, int64_t strip_first, int64_t strip_stride, double kmax,
-                            const void* V, int64_t k, int64_t ldv, double alpha, void* Y, int64_t ldy, void* ws,
-                            size_t ws_bytes, void* stream) {
+static int symm_gemm_impl(const void* Kp, int64_t n, int64_t strip_first, int64_t strip_stride, double kmax, const void* V,
+                          int64_t k, int64_t ldv, double alpha, void* Y, int64_t ldy, void* ws, size_t ws_bytes, void* stream,
+                          int rhs_pieces) {
     clear_error();
     RK_REQUIRE(Kp && V && Y, "rk_symm_gemm: null pointer");
     RK_REQUIRE(k <= 1024, "rk_symm_gemm: at most 1024 columns per call (got %lld)", (long long)k);
@@ -1178,7 +1182,7 @@ extern "C" int rk_symm_gemm(const void* Kp, int64_t n, int64_t strip_first, int6
     RK_REQUIRE(strip_stride >= 1 && strip_first >= 0 && strip_first < strip_stride, "rk_symm_gemm: bad strip distribution");
     RK_REQUIRE(kmax > 0.0 && kmax < 1e30, "rk_symm_gemm: kmax must bound the stored entries (got %g)", kmax);
     RK_REQUIRE(aligned16(Kp), "rk_symm_gemm: the packed matrix must be 16-byte aligned");
-    const bool bf = sg_use_bf16x3();
+    const bool bf = sg_use_bf16x3() && rhs_pieces != 1;
     const size_t need = rk_symm_gemm_ws_bytes(n, k);
     if (ws == nullptr || ws_bytes < need) {
         set_error("rk_symm_gemm: workspace %zu B < required %zu B", ws_bytes, need);
@@ -1206,6 +1210,9 @@ extern "C" int rk_symm_gemm(const void* Kp, int64_t n, int64_t strip_first, int6
     if (bf)
         hipLaunchKernelGGL(sg_split_rhs_kernel<SgBf16>, sgrid, dim3(256), 0, st, (const float*)V, n, npad, k, kpad, ldv, tn,
                            info, img);
+    else if (rhs_pieces == 1)
+        hipLaunchKernelGGL((sg_split_rhs_kernel<SgF16, 1>), sgrid, dim3(256), 0, st, (const float*)V, n, npad, k, kpad, ldv,
+                           tn, info, img);
     else
         hipLaunchKernelGGL(sg_split_rhs_kernel<SgF16>, sgrid, dim3(256), 0, st, (const float*)V, n, npad, k, kpad, ldv, tn,
                            info, img);
@@ -1240,15 +1247,15 @@ extern "C" int rk_symm_gemm(const void* Kp, int64_t n, int64_t strip_first, int6
         hipLaunchKernelGGL((symgemm_kernel<FMT, NCBV>), grid, dim3(SG_THREADS), smem, st, (const float*)Kp, L, img, nct, \
                            sa, info, k, (float*)Y, ldy, fold_mask);                                                      \
     } while (0)
-#define RK_SGPH(NCBV)                                                                                            \
+#define RK_SGPH(NCBV, NSBV)                                                                                      \
     do {                                                                                                         \
-        constexpr size_t smem = 2 * 2 * SG_TM * SG_ROWB + 4 * 2 * 32 * NCBV * SG_ROWB;                           \
+        constexpr size_t smem = 2 * 2 * SG_TM * SG_ROWB + 4 * NSBV * 32 * NCBV * SG_ROWB;                        \
         static std::atomic<unsigned long long> attr_devs{0};                                                     \
         int dev_ = 0;                                                                                            \
         (void)hipGetDevice(&dev_);                                                                               \
         const unsigned long long bit_ = 1ull << (dev_ & 63);                                                     \
         if (!(attr_devs.load(std::memory_order_acquire) & bit_)) {                                               \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(symgemm_ph_kernel<NCBV>),                      \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(symgemm_ph_kernel<NCBV, NSBV>),                      \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {      \
                 (void)hipGetLastError();                                                                         \
                 set_error("rk_symm_gemm: cannot reserve %zu bytes of LDS", smem);                                \
@@ -1256,12 +1263,15 @@ extern "C" int rk_symm_gemm(const void* Kp, int64_t n, int64_t strip_first, int6
             }                                                                                                    \
             attr_devs.fetch_or(bit_, std::memory_order_release);                                                 \
         }                                                                                                        \
-        hipLaunchKernelGGL((symgemm_ph_kernel<NCBV>), grid, dim3(SG_THREADS), smem, st, (const float*)Kp, L, img, nct, \
+        hipLaunchKernelGGL((symgemm_ph_kernel<NCBV, NSBV>), grid, dim3(SG_THREADS), smem, st, (const float*)Kp, L, img, nct, \
                            sa, info, k, (float*)Y, ldy, fold_mask);                                                    \
     } while (0)
-    if (!bf && sg_use_phases()) {
-        if (tn == 256) RK_SGPH(8);
-        else RK_SGPH(4);
+    if (!bf && rhs_pieces == 1) {
+        if (tn == 256) RK_SGPH(8, 1);
+        else RK_SGPH(4, 1);
+    } else if (!bf && sg_use_phases()) {
+        if (tn == 256) RK_SGPH(8, 2);
+        else RK_SGPH(4, 2);
     } else if (bf) {
         if (tn == 256) RK_SG(SgBf16, 8);
         else RK_SG(SgBf16, 4);
@@ -1272,6 +1282,18 @@ extern "C" int rk_symm_gemm(const void* Kp, int64_t n, int64_t strip_first, int6
 #undef RK_SG
 #undef RK_SGPH
     return launch_status("rk_symm_gemm");
+}
+
+extern "C" int rk_symm_gemm(const void* Kp, int64_t n, int64_t strip_first, int64_t strip_stride, double kmax,
+                            const void* V, int64_t k, int64_t ldv, double alpha, void* Y, int64_t ldy, void* ws,
+                            size_t ws_bytes, void* stream) {
+    return symm_gemm_impl(Kp, n, strip_first, strip_stride, kmax, V, k, ldv, alpha, Y, ldy, ws, ws_bytes, stream, 2);
+}
+
+extern "C" int rk_symm_gemm_rhs16(const void* Kp, int64_t n, int64_t strip_first, int64_t strip_stride, double kmax,
+                                  const void* V, int64_t k, int64_t ldv, double alpha, void* Y, int64_t ldy, void* ws,
+                                  size_t ws_bytes, void* stream) {
+    return symm_gemm_impl(Kp, n, strip_first, strip_stride, kmax, V, k, ldv, alpha, Y, ldy, ws, ws_bytes, stream, 1);
 }
 
 // ---- the fused evaluate-and-multiply product (matrix-free operators) -------------------------------------------------

@@ -41,7 +41,7 @@ from .. import dist as _dist
 from ..linops import LinOp, ScaleMixin, TwoSidedLinOp
 from ..linops.base import _RemoteShard
 from ..linops.distributed import _DistributedLinOp, _DistributedTwoSidedLinOp
-from ..ops import get_backend
+from ..ops import get_backend, on_f16_grid
 from ..utils import _is_set, _is_torch_tensor
 from .configs import KernelConfig, _is_kernel_config
 
@@ -178,9 +178,10 @@ class _SymPackBlock:
         16-bit matrix cores - no row-major panels, no second evaluation of the entries; complete when
         stride == 1.  float64 x over float32 storage: the product runs in float32 (as the panel route does)."""
         be = get_backend()
+        grid = on_f16_grid(x)  # (a test matrix drawn on the float16 grid: one piece, two products per pair)
         xs = x if x.dtype == torch.float32 else x.float()
         outs = [be.symm_gemm(self.Kp, self.n, xs[:, c0 : c0 + 1024], kmax=abs(self.scale), first=self.first,
-                             stride=self.stride, tag="kernel_sketch_product")
+                             stride=self.stride, tag="kernel_sketch_product", rhs_f16=grid)
                 for c0 in range(0, xs.shape[1], 1024)]
         out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
         return out.to(x.dtype)
@@ -293,6 +294,7 @@ class _KernelBlock:
         parts = min(parts, max(1, -(-n // 256)))
         cap = max(be.sympack_elems(n, f, parts) for f in range(parts))
         buf = torch.empty(cap, dtype=torch.float32, device=x.device)
+        grid = on_f16_grid(x)
         xs = x if x.dtype == torch.float32 else x.float()
         out = None
         for f in range(parts):
@@ -300,7 +302,7 @@ class _KernelBlock:
                                         stride=parts, out=buf)
             for c0 in range(0, xs.shape[1], 1024):
                 part = be.symm_gemm(Kp, n, xs[:, c0 : c0 + 1024], kmax=abs(self.scale), first=f, stride=parts,
-                                    tag="kernel_sketch_product")
+                                    tag="kernel_sketch_product", rhs_f16=grid)
                 if out is None:
                     out = torch.zeros((n, xs.shape[1]), dtype=torch.float32, device=x.device)
                 out[:, c0 : c0 + 1024] += part

@@ -68,6 +68,19 @@ def _as2d(v):
     return (v[:, None], True) if v.ndim == 1 else (v, False)
 
 
+def f16_grid(x: torch.Tensor) -> torch.Tensor:
+    """x rounded to the float16 grid (kept in x's dtype) and tagged: products that split their operands into
+    float16 pieces then need ONE piece of it (``symm_gemm(rhs_f16=True)``).  The tag is a Python attribute of this
+    tensor object: slices and copies lose it (and then simply take the general path)."""
+    y = x.to(torch.float16).to(x.dtype)
+    y._rk_f16_grid = True
+    return y
+
+
+def on_f16_grid(x) -> bool:
+    return bool(getattr(x, "_rk_f16_grid", False))
+
+
 class HipBackend:
     """The product compute backend: every method is one or two kernel launches."""
 
@@ -362,10 +375,11 @@ class HipBackend:
             _lib.check(rc, "rk_symm_matmat")
         return out[:, 0] if squeeze else out
 
-    def symm_gemm(self, Kp, n, V, kmax=1.0, alpha=1.0, first=0, stride=1, tag=None):
+    def symm_gemm(self, Kp, n, V, kmax=1.0, alpha=1.0, first=0, stride=1, tag=None, rhs_f16=False):
         """alpha * (this rank's partial of) K V for MANY columns (the sketch product Y = K Omega), from
         the float32 packed triangle in place, on the 16-bit matrix cores (``rk_symm_gemm``).  ``kmax``
-        bounds the magnitude of the stored entries (the operator's const_scaling)."""
+        bounds the magnitude of the stored entries (the operator's const_scaling).  ``rhs_f16``: V is on
+        the float16 grid (``f16_grid``): one piece of V, two products per pair (``rk_symm_gemm_rhs16``)."""
         dev = _req(Kp, V)
         if Kp.dtype != torch.float32 or V.dtype != torch.float32 or V.ndim != 2 or V.shape[0] != n:
             raise ValueError("symm_gemm: float32 packed matrix and a float32 n x k block")
@@ -376,8 +390,9 @@ class HipBackend:
         # (its own buffer: the split image of V is hundreds of MB - not something to pin in the shared workspace)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         with self._timed(tag or "rk_symm_gemm", dev, 2 * Kp.numel() * 4 + 2 * n * k * 4):
-            rc = self._lib.rk_symm_gemm(_ptr(Kp), n, first, stride, float(kmax), _ptr(V2), k, ldv, float(alpha),
-                                        _ptr(out), k, _ptr(ws), nbytes, _stream(dev))
+            fn = self._lib.rk_symm_gemm_rhs16 if rhs_f16 else self._lib.rk_symm_gemm
+            rc = fn(_ptr(Kp), n, first, stride, float(kmax), _ptr(V2), k, ldv, float(alpha), _ptr(out), k, _ptr(ws),
+                    nbytes, _stream(dev))
         _lib.check(rc, "rk_symm_gemm")
         return out
 

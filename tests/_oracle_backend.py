@@ -61,7 +61,9 @@ class OracleBackend:
             out[:, step * k :] = tail.reshape(-1).to(part.dtype)
         return out
 
-    def symm_gemm(self, Kp, n, V, kmax=1.0, alpha=1.0, first=0, stride=1, tag=None):
+    def symm_gemm(self, Kp, n, V, kmax=1.0, alpha=1.0, first=0, stride=1, tag=None, rhs_f16=False):
+        if rhs_f16:  # (rk_symm_gemm_rhs16 rounds V to the float16 grid)
+            V = V.to(torch.float16).to(V.dtype)
         return self.symm_matmat(Kp, n, V, alpha=alpha, first=first, stride=stride)
 
     def matmat(self, A, V, alpha=1.0, beta=0.0, C=None, diag_shift=0.0, row0=0, tag=None):

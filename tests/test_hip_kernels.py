@@ -904,6 +904,43 @@ def test_symm_gemm_wide_product_from_the_packed_strips(be, monkeypatch, n, k, fi
         assert float((got2 - want2).norm() / want2.norm()) < 5e-6
 
 
+@pytest.mark.parametrize("n,k,first,stride", [(1000, 40, 0, 1), (3000, 256, 0, 1), (5000, 512, 0, 1), (4100, 130, 1, 3),
+                                             (700, 17, 0, 1), (1100, 1024, 0, 1), (2100, 700, 2, 5), (90, 33, 0, 1)])
+@pytest.mark.parametrize("impl", ["ph", "lockstep"])
+def test_symm_gemm_with_a_block_on_the_float16_grid(be, monkeypatch, n, k, first, stride, impl):
+    """rk_symm_gemm_rhs16: a V on the float16 grid has ONE piece - two products per pair.  On such a V the general
+    entry adds exact zeros for the missing piece, in the same order: the two results are equal bit for bit; the
+    float64 product bounds both.  A V off the grid is rounded to it (per column, after the kernel's scaling).  (RK_SYMGEMM_IMPL only selects the kernel of the
+    general entry: both of them against the one-piece kernel.)"""
+    from rlaopt_amd.ops import f16_grid, on_f16_grid
+
+    monkeypatch.setenv("RK_SYMGEMM_IMPL", impl)
+    dt = torch.float32
+    g = torch.Generator().manual_seed(7 * n + k)
+    X = torch.randn(n, 6, dtype=dt, generator=g) / 6**0.5
+    scale = 0.75
+    raw = torch.randn(n, k, dtype=dt, generator=g) * torch.logspace(-5, 2, k, dtype=dt) / k**0.5
+    V = f16_grid(raw)
+    assert on_f16_grid(V) and not on_f16_grid(raw) and torch.equal(V, V.half().float())
+    Kd = ok.kernel_matrix("rbf", X.double(), X.double(), 1.0, scale)
+    Xd = X.to(dev())
+    Kp = be.sympack_materialize("rbf", Xd, 1.0, scale=scale, first=first, stride=stride)
+    one = be.symm_gemm(Kp, n, V.to(dev()), kmax=scale, first=first, stride=stride, rhs_f16=True)
+    two = be.symm_gemm(Kp, n, V.to(dev()), kmax=scale, first=first, stride=stride)
+    assert torch.equal(one, two)
+    # off the grid: rounded to float16 AFTER the kernel's power-of-two scaling of the column (largest entry below 2^14:
+    # a column of small numbers keeps 11 bits where a plain .half() would make subnormals of them)
+    ex = torch.frexp(raw.abs().amax(dim=0))[1]
+    up = torch.ldexp(torch.ones(k), 14 - ex)
+    rounded = (raw * up).half().float() / up
+    got = be.symm_gemm(Kp, n, raw.to(dev()), kmax=scale, first=first, stride=stride, rhs_f16=True)
+    assert torch.equal(got, be.symm_gemm(Kp, n, rounded.to(dev()), kmax=scale, first=first, stride=stride))
+    if stride == 1:
+        want = Kd @ V.double()
+        err = (one.cpu().double() - want).norm(dim=0) / want.norm(dim=0)
+        assert float(err.max()) < 5e-6, (float(err.max()), int(err.argmax()))
+
+
 @pytest.mark.parametrize("name,kind", [("RBF", "rbf"), ("Laplace", "laplace"), ("Matern12", "matern12"),
                                        ("Matern32", "matern32"), ("Matern52", "matern52")])
 def test_integration_md_stub_runs_against_the_oracle(be, prec, name, kind):

@@ -16,9 +16,9 @@ from rlaopt_amd.ops import get_backend  # noqa: E402
 
 
 def run(be, impl, *a, **k):
-    os.environ["RK_SYMGEMM_IMPL"] = impl
+    os.environ["RK_SYMGEMM_IMPL"] = "ph" if impl == "rhs16" else impl
     try:
-        return be.symm_gemm(*a, **k)
+        return be.symm_gemm(*a, rhs_f16=(impl == "rhs16"), **k)  # ("rhs16": the one-piece kernel, V rounded to its grid)
     finally:
         del os.environ["RK_SYMGEMM_IMPL"]
 
@@ -57,7 +57,7 @@ def main():
     X = (torch.randn(n, 64, dtype=torch.float64, generator=g) / 8).float().to(dev)
     Kp = be.sympack_materialize("rbf", X, 1.0, first=0, stride=args.stride)
     for r in args.r:
-        Om = (torch.randn(n, r, generator=g) / r**0.5).to(dev)
+        Om = (torch.randn(n, r, generator=g) / r**0.5).half().float().to(dev)  # (on the float16 grid: every kernel agrees)
         ref = None
         for rd in range(args.rounds):
             for impl in args.impls:

@@ -72,28 +72,42 @@ def main():
             err = float(((Yo[rows].double() - want).norm(dim=0) / want.norm(dim=0)).max())
             print(f"r={r:4d} panels + rk_gemm (float32 MFMA): {ms:8.2f} ms, max column error vs float64 {err:.2e}", flush=True)
             del panel, Yo
-        for split, fold in [("f16x2", a) for a in args.fold] + [("bf16x3", args.fold[0])]:
+        from rlaopt_amd.ops import f16_grid
+
+        Omg = f16_grid(Om)  # the test matrix as the Gaussian sketch draws it: on the float16 grid
+        wantg = None
+        variants = ([("f16x2", a, "ph", False) for a in args.fold] + [("f16x2", args.fold[0], "lockstep", False),
+                    ("f16x2", args.fold[0], "ph", True), ("bf16x3", args.fold[0], "lockstep", False)])
+        for split, fold, impl, grid in variants:
             os.environ["RK_SYMGEMM_FOLD"] = str(fold)
+            os.environ["RK_SYMGEMM_IMPL"] = impl
             if split == "bf16x3":
                 os.environ["RK_SYMGEMM_SPLIT"] = "bf16x3"
             else:
                 os.environ.pop("RK_SYMGEMM_SPLIT", None)
-            Y = be.symm_gemm(Kp, n, Om)
+            V = Omg if grid else Om
+            Y = be.symm_gemm(Kp, n, V, rhs_f16=grid)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(args.reps):
-                Y = be.symm_gemm(Kp, n, Om)
+                Y = be.symm_gemm(Kp, n, V, rhs_f16=grid)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.reps
-            terms = 3 if split == "f16x2" else 6
+            terms = 6 if split == "bf16x3" else (2 if grid else 3)
             if want is None:  # (after the timing: float64 GEMMs right before it lower the clocks the kernel gets)
                 want = be.kernel_materialize("rbf", X[rows].double(), X.double(), 1.0) @ Om.double()
-            err = float(((Y[rows].double() - want).norm(dim=0) / want.norm(dim=0)).max())
-            print(f"r={r:4d} {split} fold {fold:3d}: {ms:8.2f} ms  {2 * n * n * r / ms / 1e9:7.1f} TFLOP/s float32-equivalent, "
+            if grid and wantg is None:
+                wantg = be.kernel_materialize("rbf", X[rows].double(), X.double(), 1.0) @ Omg.double()
+            w = wantg if grid else want
+            err = float(((Y[rows].double() - w).norm(dim=0) / w.norm(dim=0)).max())
+            label = (f"{split} fold {fold:3d} " + ("one piece of V (on the float16 grid), phase kernel" if grid else
+                     ("phase kernel" if impl == "ph" and split == "f16x2" else "lockstep kernel")))
+            print(f"r={r:4d} {label}: {ms:8.2f} ms  {2 * n * n * r / ms / 1e9:7.1f} TFLOP/s float32-equivalent, "
                   f"{terms * 2 * n * n * max(r, 128) / ms / 1e9:7.1f} TFLOP/s on the 16-bit cores (padded), "
                   f"max column error vs float64 {err:.2e}", flush=True)
+        os.environ.pop("RK_SYMGEMM_IMPL", None)
         del Om, Y, want
     os.environ.pop("RK_SYMGEMM_SPLIT", None)
     os.environ.pop("RK_SYMGEMM_FOLD", None)

@@ -56,7 +56,7 @@ timeout -k 10 300 python3 bench.py --n 50000 --d 32 --steps 200 --warmup 20 --no
 # the sketch product from the packed strips (rk_symm_gemm): timing, error, SQ counters; the Nystrom assembly by stage
 timeout -k 10 300 python3 tools/bench_symgemm.py --fold 16 > $OUT/${TAG}_bench_symgemm.log 2>&1 && echo "symgemm ok"
 timeout -k 10 300 python3 tools/profile_nystrom_setup.py > $OUT/${TAG}_nystrom_setup.log 2>&1 && echo "nystrom setup ok"
-bash tools/pmc_symgemm.sh ${TAG} > $OUT/${TAG}_pmc_symgemm.log 2>&1 && python3 tools/pmc_table.py $OUT/${TAG}_sq symgemm_kernel > $OUT/${TAG}_symgemm_sq_counters.txt && echo "pmc symgemm ok"
+bash tools/pmc_symgemm.sh ${TAG} > $OUT/${TAG}_pmc_symgemm.log 2>&1 && python3 tools/pmc_table.py $OUT/${TAG}_sq symgemm_ > $OUT/${TAG}_symgemm_sq_counters.txt && echo "pmc symgemm ok"
 # ASkotch end to end (300 iterations, callback_freq 100): residual trajectory
 timeout -k 10 300 python3 tools/bench_sap.py --solve > $OUT/${TAG}_sap_solve.log 2>&1 && echo "sap solve ok" && tail -1 $OUT/${TAG}_sap_solve.log | cut -c1-300
 # rehearsal of the multi-rank path: two gloo ranks sharing this one GPU (n = 100 000)

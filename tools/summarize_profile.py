@@ -101,14 +101,16 @@ with open(f"{dst}/{tag}_summary.md", "w") as f:
     # matrix-core evidence: the Nystrom sketch product Y = K Omega (rk_symm_gemm: float16 split on the 16-bit cores)
     import re as _re
     mwl = _re.search(r"n=(\d+) d=\d+ k=\d+ nystrom_rank=(\d+)", bench["config"]["workload"])
-    gem = [r for r in rows if "symgemm_kernel" in r["Name"]]
+    gem = [r for r in rows if "symgemm_" in r["Name"]]
     if mwl and gem:
         nn, rr = int(mwl.group(1)), int(mwl.group(2))
         flops = 2.0 * nn * nn * rr / bench["n_gpus"]  # float32-equivalent, per launch
         md = med.get(gem[0]["Name"], (float(gem[0]["AverageNs"]) / 1e3, 0.0))[0] * 1e-6  # s
-        terms = 6 if "SgBf16" in gem[0]["Name"] else 3
+        one_piece = "symgemm_ph_kernel<8, 1>" in gem[0]["Name"] or "symgemm_ph_kernel<4, 1>" in gem[0]["Name"]
+        terms = 6 if "SgBf16" in gem[0]["Name"] else (2 if one_piece else 3)
         f.write("## Matrix cores: the Nystrom sketch product Y = K Omega from the packed strips (`rk_symm_gemm`)\n\n")
-        f.write(f"`symgemm_kernel`: {sum(int(r['Calls']) for r in gem)} launches (assembly + its warm repeat), median {md * 1e3:.1f} ms for "
+        f.write(f"`{gem[0]['Name'][:gem[0]['Name'].find('(')].replace('void rk::', '')}`"
+                f"{' (Omega on the float16 grid: one piece, two products per pair)' if one_piece else ''}: {sum(int(r['Calls']) for r in gem)} launches (assembly + its warm repeat), median {md * 1e3:.1f} ms for "
                 f"2 n^2 r = {flops:.3e} flop float32-equivalent -> **{flops / md / 1e12:.0f} TFLOP/s float32-equivalent = "
                 f"{terms * flops / md / 1e15:.2f} PFLOP/s on the 16-bit matrix cores** ({terms} exact products per pair; "
                 f"{100 * terms * flops / md / 2.5e15:.0f} % of their 2.5 PFLOP/s dense peak).\n\n")
@@ -116,7 +118,7 @@ with open(f"{dst}/{tag}_summary.md", "w") as f:
     if os.path.exists(mf) and gem:
         acc = {}
         for r in csv.DictReader(open(mf)):
-            if "symgemm_kernel" in r["Kernel_Name"]:
+            if "symgemm_" in r["Kernel_Name"]:
                 acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
         if acc.get("SQ_VALU_MFMA_BUSY_CYCLES") and acc.get("GRBM_GUI_ACTIVE"):
             busy = sum(acc["SQ_VALU_MFMA_BUSY_CYCLES"])
