@@ -52,7 +52,15 @@ def make_problem(n, d, r, dt, seed_x=0, seed_om=1):
     Om = torch.empty(n, r, dtype=dt)
     for c0 in range(0, r, 64):  # randn(r, n)/sqrt(r) transposed, drawn in slabs to bound memory
         Om[:, c0 : c0 + 64] = (torch.randn(min(64, r - c0), n, dtype=torch.float64, generator=g) / r**0.5).T.to(dt)
-    return X, B, Om
+    # on the float16 grid, as the package's own Gaussian sketch is drawn (rlaopt_amd/sketches: the sketch product then splits
+    # Omega into one float16 piece); on_grid() re-attaches the tag after a copy to the device
+    return X, B, Om.to(torch.float16).to(dt)
+
+
+def on_grid(Om):
+    from rlaopt_amd.ops import f16_grid
+
+    return f16_grid(Om)
 
 
 def es_of(dt):
@@ -157,7 +165,7 @@ def cpu_baseline(X, n, d, r, callback_freq, dev, budget_s=30.0):
     A = RBFLinOp(Xg, Xg, KernelConfig(lengthscale=1.0))
     cfg = PCGConfig(device=dev, max_iters=max_iters, atol=0.0, rtol=1e-6,
                     precond_config=NystromConfig(rank=r_c, rho=reg, sketch="gauss"))
-    with sketches.inject(Omc.to(dev)):
+    with sketches.inject(on_grid(Omc.to(dev))):
         Wg, log = LinSys(A, Bc.to(dev), reg=reg).solve(cfg, torch.zeros(n_cpu, 1, dtype=dt, device=dev),
                                                        callback_freq=callback_freq)
     torch.cuda.synchronize()
@@ -327,7 +335,7 @@ def main():
     dt = torch.float32 if args.dtype == "f32" else torch.float64
     es = 4 if args.dtype == "f32" else 8
     X, B, Om = make_problem(n, d, r, dt)
-    Xd, Bd, Omd = X.to(dev), B.to(dev), Om.to(dev)
+    Xd, Bd, Omd = X.to(dev), B.to(dev), on_grid(Om.to(dev))
 
     def sync():
         torch.cuda.synchronize()
@@ -481,7 +489,7 @@ def main():
         system2 = LinSys(A, Bd, reg=reg)
         cfg = PCGConfig(device=dev, max_iters=200, atol=0.0, rtol=1e-6,
                         precond_config=NystromConfig(rank=r, rho=reg, sketch="gauss"))
-        Omd = Om.to(dev)
+        Omd = on_grid(Om.to(dev))
         sync()
         t0 = time.time()
         with sketches.inject(Omd):
@@ -515,7 +523,7 @@ def main():
             sys64 = LinSys(A64, Bd.double(), reg=reg)
             cfg = PCGConfig(device=dev, max_iters=200, atol=0.0, rtol=1e-6,
                             precond_config=NystromConfig(rank=r, rho=reg, sketch="gauss"))
-            Om64 = Om.to(dev).double()
+            Om64 = on_grid(Om.to(dev).double())
             with sketches.inject(Om64):
                 W64, log64 = sys64.solve(cfg, torch.zeros(n, k, dtype=torch.float64, device=dev),
                                          callback_freq=args.callback_freq)

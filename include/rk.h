@@ -213,6 +213,11 @@ int rk_kernel_sketch_matmat(int kind, const void* X1, int64_t n1, int64_t ldx1, 
                             int64_t ldx2, int64_t d, double ell_scalar, const void* ell_vec, const void* center,
                             double scale, const void* V, int64_t k, int64_t ldv, double alpha, void* Y, int64_t ldy,
                             void* ws, size_t ws_bytes, void* stream);
+/* The same product for a V on the float16 grid (see rk_symm_gemm_rhs16): one piece of V, two products per pair. */
+int rk_kernel_sketch_matmat_rhs16(int kind, const void* X1, int64_t n1, int64_t ldx1, const void* X2, int64_t n2,
+                            int64_t ldx2, int64_t d, double ell_scalar, const void* ell_vec, const void* center,
+                            double scale, const void* V, int64_t k, int64_t ldv, double alpha, void* Y, int64_t ldy,
+                            void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Transport  [a5, e]: RCCL behind the C ABI, one communicator per rank (one rank per GPU).

@@ -88,6 +88,11 @@ SIGNATURES = {
         [c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_void_p,
          c_double, c_void_p, c_int64, c_int64, c_double, c_void_p, c_int64, c_void_p, c_size_t, c_void_p],
     ),
+    "rk_kernel_sketch_matmat_rhs16": (
+        c_int,
+        [c_int, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_void_p,
+         c_double, c_void_p, c_int64, c_int64, c_double, c_void_p, c_int64, c_void_p, c_size_t, c_void_p],
+    ),
     "rk_nystrom_inv_apply_ws_bytes": (c_size_t, [c_int, c_int64, c_int64, c_int64]),
     "rk_nystrom_inv_apply": (
         c_int,

@@ -30,19 +30,25 @@
 // bitwise reproducible.  With cyclically dealt strips (one rank per GPU) a rank forms the contributions of
 // ITS strips to every row block: the partials of the ranks add up to K V.
 //
-// Per step and workgroup: the K tile is loaded to registers, scaled, split and written to LDS in operand
-// layout (row-major 64-byte rows, 16-byte chunks XOR-swizzled: conflict-free ds_read_b128 for the
-// 16-row x 4-chunk operand fetch); the V tile is a linear copy of a pre-split, pre-swizzled image written
-// once per call.  Two LDS buffers, loads two and three steps ahead in two register sets, one barrier per step.  Waves: 4 x 2
-// (eight per workgroup, two per SIMD: one wave's staging and waits sit beside the other's matrix-core work -
-// with four waves, one per SIMD, the matrix cores were busy 39 % of the time), each 32 rows x TN / 2 columns
-// = 2 x NCB accumulator blocks of v_mfma_f32_16x16x32_{f16,bf16}.  Measured and not kept (A/B on one box, 121.0 ms):
-// s_setprio 1 for waves 4 - 7 (120.8 ms), sched_group_barrier interleaving of operand reads and matrix-core
-// instructions (122.2 ms).  Round 4: staggering the two waves of a SIMD (waves 4 - 7 do a step's arithmetic first and
-// its staging second; legal, the staging writes the other buffer) - as a branch inside the loop 294 ms (the compiler
-// drains the prefetch queue at the joins), as two copies of the loop chosen once per phase 223 ms against 122 ms (a
-// rank's partial at p = 8: 37.9 against 20.9 ms): two different instruction streams per CU and later load issue for
-// half the waves cost far more than the lockstep it removes.
+// Per step and workgroup: the K tile is loaded to registers, scaled, split and written to LDS in operand layout
+// (row-major 64-byte rows, 16-byte chunks XOR-swizzled: conflict-free ds_read_b128 for the 16-row x 4-chunk operand
+// fetch); the V tile is a linear copy of a pre-split, pre-swizzled image written once per call.  Waves: 4 x 2 (eight per
+// workgroup, two per SIMD), each 32 rows x TN / 2 columns = 2 x NCB accumulator blocks of v_mfma_f32_16x16x32_{f16,bf16}.
+//
+// Two kernels:
+//   * symgemm_ph_kernel (default for the float16 split): two phases per step, the two waves of a SIMD half a step apart,
+//     every wait behind the matrix-core work, the V tiles by LDS-DMA - see the comment in front of it.  115 ms at
+//     n = 200 000, r = 512 against 123 - 125 ms for
+//   * symgemm_kernel (RK_SYMGEMM_IMPL=lockstep, and the three-bfloat16-piece split): two LDS buffers, loads two and three
+//     steps ahead in two register sets, one barrier per step, every wave in the same part of the step at the same time
+//     (with four waves, one per SIMD, the matrix cores were busy 39 % of the time).  Measured on it and not kept (A/B on
+//     one box, 121.0 ms): s_setprio 1 for waves 4 - 7 (120.8 ms), sched_group_barrier interleaving of operand reads and
+//     matrix-core instructions (122.2 ms); round 4: re-ordering the step's code for waves 4 - 7 - as a branch inside the
+//     loop 294 ms (the compiler drains the prefetch queue at the joins), as two copies of the loop 223 ms
+//     (profiles/r04_symgemm_stagger.log): the stagger that works keeps ONE instruction stream and delays half the waves
+//     by a barrier (symgemm_ph_kernel).
+// A V on the float16 grid (rk_symm_gemm_rhs16: the Gaussian test matrix is drawn on it) has ONE piece: two products per
+// pair, half the V bytes: 89 ms.
 #include <atomic>
 #include <stdlib.h>
 #include <type_traits>
@@ -936,7 +942,7 @@ void gram_prep_launch(const float* center, const float* ell_vec, int64_t d, floa
 void gram_split64_launch(const float* X, int64_t ldx, const int64_t* idx, int64_t n, int64_t npad, int64_t d,
                          const float* iw, const float* muw, unsigned char* img, float* norms, hipStream_t st);
 
-template <int NCB, int KIND>
+template <int NCB, int KIND, int NSB>  // NSB: pieces of V (1: V on the float16 grid, two products per pair)
 __global__ void __launch_bounds__(SG_THREADS, 2)
 kgemm_kernel(const unsigned char* __restrict__ ximg1, const float* __restrict__ xn1, int64_t n1,
              const unsigned char* __restrict__ ximg2, const float* __restrict__ xn2, int64_t n2, float w, float kscale,
@@ -947,12 +953,12 @@ kgemm_kernel(const unsigned char* __restrict__ ximg1, const float* __restrict__ 
     constexpr int TN = 32 * NCB;
     constexpr int ABYTES = SG_TM * SG_ROWB;
     constexpr int BBYTES = TN * SG_ROWB;
-    constexpr int NBQ = NS * BBYTES / 16 / SG_THREADS;
+    constexpr int NBQ = NSB * BBYTES / 16 / SG_THREADS;
     constexpr bool RBF = KIND == RK_RBF;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* AL = smem;                               // [2][NS][ABYTES]
-    unsigned char* BL = smem + 2 * NS * ABYTES;             // [2][NS][BBYTES]
-    unsigned char* XJ = BL + 2 * NS * BBYTES;               // [3][KG_SLOT]
+    unsigned char* BL = smem + 2 * NS * ABYTES;             // [2][NSB][BBYTES]
+    unsigned char* XJ = BL + 2 * NSB * BBYTES;              // [3][KG_SLOT]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 15, lq = lane >> 4;
@@ -1023,7 +1029,7 @@ kgemm_kernel(const unsigned char* __restrict__ ximg1, const float* __restrict__ 
     };
     auto load_c = [&](int64_t q, Stage& st) {
         q = clampq(q);
-        const sg_u4* src = reinterpret_cast<const sg_u4*>(img + ((q * nct + ct) * NS) * (int64_t)BBYTES);
+        const sg_u4* src = reinterpret_cast<const sg_u4*>(img + ((q * nct + ct) * NSB) * (int64_t)BBYTES);
 #pragma unroll
         for (int e = 0; e < NBQ; ++e) st.b[e] = src[tid + SG_THREADS * e];
         load_xj(q + 1, st.xj, st.nj);
@@ -1032,7 +1038,7 @@ kgemm_kernel(const unsigned char* __restrict__ ximg1, const float* __restrict__ 
     // slot q % 3, which an earlier stage filled before the last barrier - into AL[buf]
     auto store_c = [&](int buf, int64_t q, const Stage& st) {
         store_xj(q + 1, st.xj, st.nj);
-        sg_u4* dstb = reinterpret_cast<sg_u4*>(BL + buf * NS * BBYTES);
+        sg_u4* dstb = reinterpret_cast<sg_u4*>(BL + buf * NSB * BBYTES);
 #pragma unroll
         for (int e = 0; e < NBQ; ++e) dstb[tid + SG_THREADS * e] = st.b[e];
         const unsigned char* slot = XJ + (int)(q % 3) * KG_SLOT;
@@ -1083,7 +1089,7 @@ kgemm_kernel(const unsigned char* __restrict__ ximg1, const float* __restrict__ 
     const int b_off = (wc * (TN / 2) + lr) * SG_ROWB + (sg_swz(lr, lq) << 4);
     auto compute = [&](int buf) {
         const unsigned char* al = AL + buf * NS * ABYTES + a_off;
-        const unsigned char* bl = BL + buf * NS * BBYTES + b_off;
+        const unsigned char* bl = BL + buf * NSB * BBYTES + b_off;
         sg_u4 af[SG_RB][NS];
 #pragma unroll
         for (int r = 0; r < SG_RB; ++r)
@@ -1092,13 +1098,13 @@ kgemm_kernel(const unsigned char* __restrict__ ximg1, const float* __restrict__ 
                 af[r][pc] = *reinterpret_cast<const sg_u4*>(al + r * 16 * SG_ROWB + pc * ABYTES);
 #pragma unroll
         for (int c = 0; c < NCB; ++c) {
-            sg_u4 bf[NS];
+            sg_u4 bf[NSB];
 #pragma unroll
-            for (int pc = 0; pc < NS; ++pc) bf[pc] = *reinterpret_cast<const sg_u4*>(bl + c * 16 * SG_ROWB + pc * BBYTES);
+            for (int pc = 0; pc < NSB; ++pc) bf[pc] = *reinterpret_cast<const sg_u4*>(bl + c * 16 * SG_ROWB + pc * BBYTES);
 #pragma unroll
             for (int r = 0; r < SG_RB; ++r) {
                 acc[r][c] = F::mfma(af[r][1], bf[0], acc[r][c]);
-                acc[r][c] = F::mfma(af[r][0], bf[1], acc[r][c]);
+                if constexpr (NSB == 2) acc[r][c] = F::mfma(af[r][0], bf[NSB - 1], acc[r][c]);
                 acc[r][c] = F::mfma(af[r][0], bf[0], acc[r][c]);
             }
         }
@@ -1307,10 +1313,10 @@ extern "C" size_t rk_kernel_sketch_ws_bytes(int64_t n1, int64_t n2, int64_t k) {
     return SG_INFO_BYTES + sg_image_bytes(n2, k, 2) + 1024 + kg_x_bytes(n1) + kg_x_bytes(n2);
 }
 
-extern "C" int rk_kernel_sketch_matmat(int kind, const void* X1, int64_t n1, int64_t ldx1, const void* X2, int64_t n2,
-                                       int64_t ldx2, int64_t d, double ell_scalar, const void* ell_vec,
-                                       const void* center, double scale, const void* V, int64_t k, int64_t ldv,
-                                       double alpha, void* Y, int64_t ldy, void* ws, size_t ws_bytes, void* stream) {
+static int kernel_sketch_impl(int kind, const void* X1, int64_t n1, int64_t ldx1, const void* X2, int64_t n2, int64_t ldx2,
+                              int64_t d, double ell_scalar, const void* ell_vec, const void* center, double scale,
+                              const void* V, int64_t k, int64_t ldv, double alpha, void* Y, int64_t ldy, void* ws,
+                              size_t ws_bytes, void* stream, int rhs_pieces) {
     clear_error();
     RK_REQUIRE(X1 && X2 && V && Y && center, "rk_kernel_sketch_matmat: null pointer (the centre is required)");
     RK_REQUIRE(kind == RK_RBF || kind == RK_MATERN32 || kind == RK_MATERN52,
@@ -1350,8 +1356,12 @@ extern "C" int rk_kernel_sketch_matmat(int kind, const void* X1, int64_t n1, int
     hipLaunchKernelGGL(sg_absmax_kernel, dim3((unsigned)ceil_div(k, 64), 512), dim3(256), 0, st, (const float*)V, n2, k,
                        ldv, info);
     hipLaunchKernelGGL(sg_scale_kernel, dim3((unsigned)ceil_div(kpad, 256)), dim3(256), 0, st, info, kpad, ea, (float)alpha, 1);
-    hipLaunchKernelGGL(sg_split_rhs_kernel<SgF16>, dim3((unsigned)ceil_div((npadv / 8) * kpad, 256)), dim3(256), 0, st,
-                       (const float*)V, n2, npadv, k, kpad, ldv, tn, info, img);
+    if (rhs_pieces == 1)
+        hipLaunchKernelGGL((sg_split_rhs_kernel<SgF16, 1>), dim3((unsigned)ceil_div((npadv / 8) * kpad, 256)), dim3(256), 0,
+                           st, (const float*)V, n2, npadv, k, kpad, ldv, tn, info, img);
+    else
+        hipLaunchKernelGGL(sg_split_rhs_kernel<SgF16>, dim3((unsigned)ceil_div((npadv / 8) * kpad, 256)), dim3(256), 0, st,
+                           (const float*)V, n2, npadv, k, kpad, ldv, tn, info, img);
     int rc = launch_status("rk_kernel_sketch_matmat(split)");
     if (rc != RK_OK) return rc;
     const int64_t nrb = ceil_div(n1, SG_TM);
@@ -1364,15 +1374,15 @@ extern "C" int rk_kernel_sketch_matmat(int kind, const void* X1, int64_t n1, int
         if (v >= 1 && v <= 4096 && (v & (v - 1)) == 0) fold_steps = v;
     }
     const int fold_mask = fold_steps - 1;
-#define RK_KG(NCBV, KINDV)                                                                                          \
+#define RK_KG(NCBV, KINDV, NSBV)                                                                                    \
     do {                                                                                                            \
-        constexpr size_t smem = 2 * 2 * (SG_TM * SG_ROWB + 32 * NCBV * SG_ROWB) + 3 * KG_SLOT;                      \
+        constexpr size_t smem = 2 * (2 * SG_TM * SG_ROWB + NSBV * 32 * NCBV * SG_ROWB) + 3 * KG_SLOT;               \
         static std::atomic<unsigned long long> attr_devs{0};                                                        \
         int dev_ = 0;                                                                                               \
         (void)hipGetDevice(&dev_);                                                                                  \
         const unsigned long long bit_ = 1ull << (dev_ & 63);                                                        \
         if (!(attr_devs.load(std::memory_order_acquire) & bit_)) {                                                  \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kgemm_kernel<NCBV, KINDV>),                       \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kgemm_kernel<NCBV, KINDV, NSBV>),                       \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {         \
                 (void)hipGetLastError();                                                                            \
                 set_error("rk_kernel_sketch_matmat: cannot reserve %zu bytes of LDS", smem);                        \
@@ -1380,18 +1390,40 @@ extern "C" int rk_kernel_sketch_matmat(int kind, const void* X1, int64_t n1, int
             }                                                                                                       \
             attr_devs.fetch_or(bit_, std::memory_order_release);                                                    \
         }                                                                                                           \
-        hipLaunchKernelGGL((kgemm_kernel<NCBV, KINDV>), grid, dim3(SG_THREADS), smem, st, ximg1, xn1, n1, ximg2, xn2, n2, \
+        hipLaunchKernelGGL((kgemm_kernel<NCBV, KINDV, NSBV>), grid, dim3(SG_THREADS), smem, st, ximg1, xn1, n1, ximg2, xn2, n2, \
                            w, (float)scale, sa, img, nct, info, k, (float*)Y, ldy, fold_mask);                      \
     } while (0)
-#define RK_KG_KIND(NCBV)                                                \
-    do {                                                                \
-        if (kind == RK_RBF) RK_KG(NCBV, RK_RBF);                        \
-        else if (kind == RK_MATERN32) RK_KG(NCBV, RK_MATERN32);         \
-        else RK_KG(NCBV, RK_MATERN52);                                  \
+#define RK_KG_KIND(NCBV, NSBV)                                                \
+    do {                                                                      \
+        if (kind == RK_RBF) RK_KG(NCBV, RK_RBF, NSBV);                        \
+        else if (kind == RK_MATERN32) RK_KG(NCBV, RK_MATERN32, NSBV);         \
+        else RK_KG(NCBV, RK_MATERN52, NSBV);                                  \
     } while (0)
-    if (tn == 256) RK_KG_KIND(8);
-    else RK_KG_KIND(4);
+    if (rhs_pieces == 1) {
+        if (tn == 256) RK_KG_KIND(8, 1);
+        else RK_KG_KIND(4, 1);
+    } else {
+        if (tn == 256) RK_KG_KIND(8, 2);
+        else RK_KG_KIND(4, 2);
+    }
 #undef RK_KG_KIND
 #undef RK_KG
     return launch_status("rk_kernel_sketch_matmat");
+}
+
+extern "C" int rk_kernel_sketch_matmat(int kind, const void* X1, int64_t n1, int64_t ldx1, const void* X2, int64_t n2,
+                                       int64_t ldx2, int64_t d, double ell_scalar, const void* ell_vec,
+                                       const void* center, double scale, const void* V, int64_t k, int64_t ldv,
+                                       double alpha, void* Y, int64_t ldy, void* ws, size_t ws_bytes, void* stream) {
+    return kernel_sketch_impl(kind, X1, n1, ldx1, X2, n2, ldx2, d, ell_scalar, ell_vec, center, scale, V, k, ldv, alpha, Y,
+                              ldy, ws, ws_bytes, stream, 2);
+}
+
+extern "C" int rk_kernel_sketch_matmat_rhs16(int kind, const void* X1, int64_t n1, int64_t ldx1, const void* X2, int64_t n2,
+                                             int64_t ldx2, int64_t d, double ell_scalar, const void* ell_vec,
+                                             const void* center, double scale, const void* V, int64_t k, int64_t ldv,
+                                             double alpha, void* Y, int64_t ldy, void* ws, size_t ws_bytes,
+                                             void* stream) {
+    return kernel_sketch_impl(kind, X1, n1, ldx1, X2, n2, ldx2, d, ell_scalar, ell_vec, center, scale, V, k, ldv, alpha, Y,
+                              ldy, ws, ws_bytes, stream, 1);
 }

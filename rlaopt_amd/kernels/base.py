@@ -319,7 +319,8 @@ class _KernelBlock:
             # shards included
             xs = x if x.dtype == torch.float32 else x.float()
             return be.kernel_sketch_matmat(self.kind, self.A1, self.A2, self.config.lengthscale, xs, scale=self.scale,
-                                           gram_center=self.gram_center, tag="kernel_sketch_product").to(x.dtype)
+                                           gram_center=self.gram_center, tag="kernel_sketch_product",
+                                           rhs_f16=on_f16_grid(x)).to(x.dtype)
         if (self._symmetric and m == n and self.A1.dtype == torch.float32 and x.is_cuda and x.ndim == 2
                 and self.scale != 0.0 and hasattr(be, "symm_gemm") and hasattr(be, "sympack_elems")
                 and os.environ.get("RK_FREE_WIDE_STRIPS", "1") != "0"):

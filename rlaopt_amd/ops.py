@@ -397,7 +397,8 @@ class HipBackend:
         return out
 
     # -- dense products ----------------------------------------------------------------
-    def kernel_sketch_matmat(self, kind, X1, X2, lengthscale, V, scale=1.0, gram_center=None, alpha=1.0, tag=None):
+    def kernel_sketch_matmat(self, kind, X1, X2, lengthscale, V, scale=1.0, gram_center=None, alpha=1.0, tag=None,
+                             rhs_f16=False):
         """alpha * scale * K(X1, X2) @ V for MANY columns with the kernel entries evaluated inside the product
         (``rk_kernel_sketch_matmat``: float32, d <= 64, rbf / matern32 / matern52, a ``gram_center`` from
         :meth:`gram_center` required) - the sketch product of an operator that stores nothing."""
@@ -414,7 +415,7 @@ class HipBackend:
             nbytes = self._lib.rk_kernel_sketch_ws_bytes(n1, n2, kc)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)  # (its own buffer: hundreds of MB of split images)
             with self._timed(tag or "rk_kernel_sketch_matmat", dev, 0):
-                rc = self._lib.rk_kernel_sketch_matmat(
+                rc = (self._lib.rk_kernel_sketch_matmat_rhs16 if rhs_f16 else self._lib.rk_kernel_sketch_matmat)(
                     kid, _ptr(X1), n1, ld1, _ptr(X2), n2, ld2, X1.shape[1], ell, _ptr(ell_vec), _ptr(gram_center),
                     float(scale), V2.data_ptr() + c0 * 4, kc, ldv, float(alpha), out.data_ptr() + c0 * 4, k, _ptr(ws),
                     nbytes, _stream(dev))

@@ -695,6 +695,13 @@ def test_kernel_sketch_matmat_evaluates_inside_the_product(be, kind, n1, n2, d, 
         be.kernel_sketch_matmat("laplace", X1d, X2d, elld, V.to(dev()), gram_center=gc)
     with pytest.raises(ValueError):
         be.kernel_sketch_matmat(kind, X1d, X2d, elld, V.to(dev()), gram_center=None)
+    # a V on the float16 grid (rk_kernel_sketch_matmat_rhs16: one piece, two products per pair): the general entry adds
+    # exact zeros for the missing piece in the same order - equal bit for bit
+    from rlaopt_amd.ops import f16_grid
+
+    Vg = f16_grid(V / k**0.5).to(dev())
+    one = be.kernel_sketch_matmat(kind, X1d, X2d, elld, Vg, scale=0.7, gram_center=gc, rhs_f16=True)
+    assert torch.equal(one, be.kernel_sketch_matmat(kind, X1d, X2d, elld, Vg, scale=0.7, gram_center=gc))
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 16, 17, 1000, 4097, 500_000])

@@ -52,6 +52,11 @@ def main():
         ms, Y = timed(lambda: be.kernel_sketch_matmat(args.kind, X, X, 1.0, Om, gram_center=gc), args.reps)
         rec["fused"] = {"ms": round(ms, 2), "TFLOPs_f32_equiv": round(2 * n * n * r / ms / 1e9, 1),
                         "TFLOPs_16bit_cores": round(3 * 2 * n * n * (max(r, 128) + 2 * d * (-(-r // 256))) / ms / 1e9, 1)}
+        from rlaopt_amd.ops import f16_grid
+
+        Omg = f16_grid(Om)  # (as the Gaussian sketch draws it: one piece of Omega, two products per pair)
+        ms_g, Yg = timed(lambda: be.kernel_sketch_matmat(args.kind, X, X, 1.0, Omg, gram_center=gc, rhs_f16=True), args.reps)
+        rec["fused_rhs16"] = {"ms": round(ms_g, 2)}
         if not args.only_fused:
             os.environ["RK_KERNEL_MODE"] = "matrix_free"
             os.environ["RK_FREE_WIDE_FUSED"] = "0"

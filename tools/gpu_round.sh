@@ -3,11 +3,20 @@
 # Usage (on the box, from the repo root): bash tools/gpu_round.sh <tag>
 set -o pipefail
 TAG=${1:-r01}
-PART=${2:-all}   # a: tests, bench, rocprof / PMC of the bench; b: the other benches; c: round-4 additions (packed multi-RHS
+PART=${2:-all}   # a: tests, bench, rocprof / PMC of the bench; b: the other benches; d: the sketch kernels only; c: round-4 additions (packed multi-RHS
                  # PMC, write-cost probe, float64 lines, self-launched two-rank rehearsal); all: everything (> 30 minutes)
 OUT=gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+if [ "$PART" = "d" ]; then  # the sketch kernels only: parity, timings, SQ counters, the assembly by stage, matrix-free PCG
+timeout -k 10 600 python -m pytest tests/test_hip_kernels.py tests/test_hip_scale.py -m gpu -q -x -k "sketch or symm_gemm or nystrom or matrix_free" > $OUT/${TAG}_pytest_sketch.log 2>&1; echo "pytest EXIT $?"; tail -2 $OUT/${TAG}_pytest_sketch.log
+timeout -k 10 300 python3 tools/bench_symgemm.py --fold 16 > $OUT/${TAG}_bench_symgemm.log 2>&1 && echo "symgemm ok"
+timeout -k 10 300 python3 tools/bench_ksketch.py > $OUT/${TAG}_bench_ksketch.log 2>&1 && echo "ksketch ok"
+timeout -k 10 300 python3 tools/profile_nystrom_setup.py > $OUT/${TAG}_nystrom_setup.log 2>&1 && echo "nystrom setup ok"
+bash tools/pmc_symgemm.sh ${TAG} > $OUT/${TAG}_pmc_symgemm.log 2>&1 && python3 tools/pmc_table.py $OUT/${TAG}_sq symgemm_ > $OUT/${TAG}_symgemm_sq_counters.txt && echo "pmc symgemm ok"
+RK_KERNEL_MODE=matrix_free timeout -k 10 300 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-solve > $OUT/${TAG}_bench_matrix_free.log 2>&1 && echo "matrix-free pcg ok"
+exit 0
+fi
 if [ "$PART" != "b" ]; then
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/${TAG}_smoke.log 2>&1; tail -1 $OUT/${TAG}_smoke.log
 timeout -k 10 800 python -m pytest tests -m gpu -q -x > $OUT/${TAG}_pytest_gpu.log 2>&1; echo "pytest EXIT $?"; tail -3 $OUT/${TAG}_pytest_gpu.log

@@ -29,7 +29,9 @@ def main():
     be = get_backend()
     n, d, r = args.n, args.d, args.rank
     X, B, Om = make_problem(n, d, r, torch.float32)
-    Xd, Omd = X.to(dev), Om.to(dev)
+    from bench import on_grid
+
+    Xd, Omd = X.to(dev), on_grid(Om.to(dev))  # (on the float16 grid, as the Gaussian sketch draws it)
     A = DistributedRBFLinOp(Xd, Xd, KernelConfig(lengthscale=1.0), devices={dev})
     A.local_matmat(torch.zeros(n, 1, device=dev))
     torch.cuda.synchronize()
