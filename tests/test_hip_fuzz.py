@@ -164,3 +164,25 @@ def test_block_symmetric_product_and_fused_sketch_random_shapes(be, monkeypatch,
     got = be.kernel_sketch_matmat(kind, Xd, X2d, 1.1, Om.to(DEV), scale=scale, gram_center=gc)
     want2 = ok.kernel_matrix(kind, X.double(), X2.double(), 1.1, scale) @ Om.double()
     assert rel_err(got, want2) < 1e-5, (n, n2, d, r, kind)
+    # the sketch product from the packed strips (any cyclic distribution): phase kernel = lockstep kernel bit for bit, and
+    # for a block on the float16 grid the one-piece kernels (stored strips and fused evaluation) = the general ones
+    from rlaopt_amd.ops import f16_grid
+
+    Vw = torch.randn(n, r, generator=gen)
+    Vg = f16_grid(Vw)
+    tot = torch.zeros(n, r, dtype=torch.float64)
+    for f in range(stride):
+        Kp = be.sympack_materialize(kind, Xd, 1.1, scale=scale, first=f, stride=stride)
+        monkeypatch.setenv("RK_SYMGEMM_IMPL", "lockstep")
+        lock = be.symm_gemm(Kp, n, Vw.to(DEV), kmax=scale, first=f, stride=stride)
+        monkeypatch.setenv("RK_SYMGEMM_IMPL", "ph")
+        ph = be.symm_gemm(Kp, n, Vw.to(DEV), kmax=scale, first=f, stride=stride)
+        assert torch.equal(lock, ph), (n, r, f, stride)
+        assert torch.equal(be.symm_gemm(Kp, n, Vg.to(DEV), kmax=scale, first=f, stride=stride, rhs_f16=True),
+                           be.symm_gemm(Kp, n, Vg.to(DEV), kmax=scale, first=f, stride=stride)), (n, r, f, stride)
+        tot += ph.cpu().double()
+    wantw = Kd @ Vw.double()
+    assert float(((tot - wantw).norm(dim=0) / wantw.norm(dim=0)).max()) < 5e-6, (n, r, stride, kind)
+    Og = f16_grid(Om).to(DEV)
+    assert torch.equal(be.kernel_sketch_matmat(kind, Xd, X2d, 1.1, Og, scale=scale, gram_center=gc, rhs_f16=True),
+                       be.kernel_sketch_matmat(kind, Xd, X2d, 1.1, Og, scale=scale, gram_center=gc))
