@@ -563,6 +563,10 @@ __device__ __forceinline__ void sg_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)"
 #ifndef RK_PH_PROBE
 #define RK_PH_PROBE 0
 #endif
+#ifndef RK_SG_PF
+#define RK_SG_PF 0  // > 0: every wave touches 16 lines of the K tile this many steps ahead (one dword per line, result unused):
+                    // measured 4 / 8 / 16 steps: 110.5 / 116.8 / 117.8 against 110.4 ms (profiles/r04_symgemm_phases.log): off
+#endif
 #ifndef RK_SG_FILL
 #define RK_SG_FILL 1  // vector instructions the scheduler may place behind each matrix-core instruction of a phase M
 #endif
@@ -690,6 +694,11 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
             : "v"(p0), "v"(p1)
             : "memory");
     };
+    unsigned pfreg = 0;  // (destination of the prefetch touches: stays allocated from touch to touch)
+    auto touch_t = [&](int64_t q) {  // wave w: rows 4 w .. + 4 of the 32-row tile, 4 lines of 128 B each
+        const float* pa = Kp + (L.row_offset(tb) + q * SG_KT + wave * 4 + ((lane & 15) >> 2)) * W + ioff + (lane & 3) * 32;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(pfreg) : "v"(pa) : "memory");
+    };
     auto jstep_t = [&](int64_t q) { return q; };
     auto load_d = [&](int64_t q, StageD& st) {
         const int64_t t = t_min + q / (W / SG_KT);
@@ -706,6 +715,14 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
             : "=&v"(st.d[0]), "=&v"(st.d[1])
             : "v"(p0), "v"(p1)
             : "memory");
+    };
+    auto touch_d = [&](int64_t q) {  // wave w: rows 16 w .. + 16 of the tile, one line each
+        const int64_t t = t_min + q / (W / SG_KT);
+        const int kk = (int)(q % (W / SG_KT)) * SG_KT;
+        int64_t r = i0 + wave * 16 + (lane & 15);
+        r = r < L.n ? r : L.n - 1;
+        const float* pa = Kp + (L.row_offset(t) + r) * W + kk;
+        asm volatile("global_load_dword %0, %1, off" : "+v"(pfreg) : "v"(pa) : "memory");
     };
     auto jstep_d = [&](int64_t q) {
         const int64_t t = t_min + q / (W / SG_KT);
@@ -803,8 +820,8 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
 
     if (grp == 1 && !(RK_PH_PROBE & 8)) sg_bar();  // the second group runs one barrier behind the first from here on
 
-    auto run_phase = [&](auto load, auto jstep, auto waiter, auto split, auto store, auto& s0, auto& s1, auto& s2, auto& s3,
-                         int64_t nst) {
+    auto run_phase = [&](auto load, auto touch, auto jstep, auto waiter, auto split, auto store, auto& s0, auto& s1, auto& s2,
+                         auto& s3, int64_t nst) {
         if (nst <= 0) return;
         using Wt = decltype(waiter);
         constexpr int NA = Wt::NA;
@@ -833,6 +850,7 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
             constexpr int buf = qm & 1, slot = qm;
             const int slot2 = (qm + 2 + grp) & 3;   // the V tile this wave's DMAs fetch: q + 2 (group 0), q + 3 (group 1)
             // ---- L(q): issue only
+            if constexpr (RK_SG_PF > 0) touch(at(q + RK_SG_PF));
             if constexpr (!(RK_PH_PROBE & 4)) store(buf ^ 1, pk);     // K tile q + 1 (own rows)
             read_a(buf);
             read_bq(slot, 0, bfa);
@@ -867,7 +885,7 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
             // the waits of the step, behind its matrix-core work: K tile q + 3 and the DMAs issued in L(q - 1) have landed
             // (what L(q) issued stays in flight), this wave's LDS stores of L(q) are done
             __builtin_amdgcn_sched_barrier(0);
-            Wt::template at<NA + NBQ>(st_next);
+            Wt::template at<NA + NBQ + (RK_SG_PF > 0 ? 1 : 0)>(st_next);
             sg_lgkm0();
             sg_bar();
         };
@@ -889,11 +907,13 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
     };
     {
         StageT s0, s1, s2, s3;
-        run_phase(load_t, jstep_t, SgWaitT{}, split_t, store_t, s0, s1, s2, s3, nT);
+        run_phase(load_t, touch_t, jstep_t, SgWaitT{}, split_t, store_t, s0, s1, s2, s3, nT);
+        asm volatile("" : "+v"(pfreg));
     }
     {
         StageD s0, s1, s2, s3;
-        run_phase(load_d, jstep_d, SgWaitD{}, split_d, store_d, s0, s1, s2, s3, nD);
+        run_phase(load_d, touch_d, jstep_d, SgWaitD{}, split_d, store_d, s0, s1, s2, s3, nD);
+        asm volatile("" : "+v"(pfreg));
     }
     if (grp == 0 && !(RK_PH_PROBE & 8)) sg_bar();
 
