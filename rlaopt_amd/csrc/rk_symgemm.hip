@@ -563,13 +563,27 @@ __device__ __forceinline__ void sg_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)"
 #ifndef RK_PH_PROBE
 #define RK_PH_PROBE 0
 #endif
+#ifndef RK_SG_LATE
+#define RK_SG_LATE 0  // > 0: no vector instructions in the first half of a phase M, this many per matrix-core instruction in the second
+#endif
+#ifndef RK_SG_SPLIT_IN_L
+#define RK_SG_SPLIT_IN_L 0  // the split of the K tile in the phase L (in front of its barrier) instead of between the phase M's matrix-core instructions
+#endif
+#ifndef RK_SG_SGB
+#define RK_SG_SGB 1  // sched_group_barrier order of a phase M (0: the compiler's own)
+#endif
+#ifndef RK_SG_PRIO
+#define RK_SG_PRIO 1  // s_setprio 1 around the matrix-core work of a phase M
+#endif
 #ifndef RK_SG_PF
 #define RK_SG_PF 0  // > 0: every wave touches 16 lines of the K tile this many steps ahead (one dword per line, result unused):
                     // measured 4 / 8 / 16 steps: 110.5 / 116.8 / 117.8 against 110.4 ms (profiles/r04_symgemm_phases.log): off
 #endif
 #ifndef RK_SG_FILL
-#define RK_SG_FILL 1  // vector instructions the scheduler may place behind each matrix-core instruction of a phase M
-#endif
+#define RK_SG_FILL (-1)  // vector instructions (the split of a K tile) the scheduler places behind each matrix-core instruction
+#endif                   // of a phase M; -1: 0 with two pieces of V (the split then follows the 48 matrix-core instructions:
+                         // 102.6 against 112.3 ms with 1), 1 with one piece (84.6 against 86.3 ms with 0);
+                         // profiles/r04_symgemm_phases.log (also: no s_setprio, the compiler's own order, the split in phase L)
 
 struct SgStageT { float a[8]; };   // transposed phase: 8 rows j of one column i
 struct SgStageD { sg_u4 d[2]; };   // direct phase: 4 columns j of two rows i
@@ -810,13 +824,19 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
     };
     // the order of a quarter for the scheduler: matrix-core instructions with RK_SG_FILL vector instructions (the split
     // of a K tile) behind each - a matrix-core instruction holds the issue port for 8 of its 16 cycles
-    auto quarter_order = [&](int first, int last) {
+    auto quarter_order = [&](int first, int last, auto fill_tag) {
+        if constexpr (!RK_SG_SGB) return;
 #pragma unroll
         for (int g = first; g < last; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, RK_SG_FILL, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, decltype(fill_tag)::value, 0);
         }
     };
+    // vector instructions (the split of a K tile) behind each matrix-core instruction of the first / second half of a phase M
+    constexpr int FILL_Av = RK_SG_LATE ? 0 : (RK_SG_FILL >= 0 ? RK_SG_FILL : (NSB == 2 ? 0 : 1));
+    constexpr int FILL_Bv = RK_SG_LATE ? RK_SG_LATE : FILL_Av;
+    using FILL_A = std::integral_constant<int, FILL_Av>;
+    using FILL_B = std::integral_constant<int, FILL_Bv>;
 
     if (grp == 1 && !(RK_PH_PROBE & 8)) sg_bar();  // the second group runs one barrier behind the first from here on
 
@@ -857,12 +877,20 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
             read_bq(slot, 1, bfb);
             dma_b(jstep(at(q + 2 + grp)), slot2);
             if constexpr (!(RK_PH_PROBE & 16)) load((RK_PH_PROBE & 32) ? (q & 7) : at(q + 4), st_load);  // (bit 5: cached tiles)
+            if constexpr (RK_SG_SPLIT_IN_L) {  // the split of K tile q + 2 in the wave's idle time in front of the barrier
+                __builtin_amdgcn_sched_barrier(0);
+                pk = split(st_split);
+                if constexpr (RK_PH_PROBE & 4) pk = decltype(pk){};
+                sg_pin(pk);
+            }
             sg_bar();
             // ---- M(q): quarter 0 | reads of quarter 2 | quarter 1 | part of quarter 2 | reads of quarter 3 | rest
-            __builtin_amdgcn_s_setprio(1);
+            if constexpr (RK_SG_PRIO) __builtin_amdgcn_s_setprio(1);
             mma_q(0, bfa);
-            pk = split(st_split);
-            if constexpr (RK_PH_PROBE & 4) pk = decltype(pk){};
+            if constexpr (!RK_SG_SPLIT_IN_L) {
+                pk = split(st_split);
+                if constexpr (RK_PH_PROBE & 4) pk = decltype(pk){};
+            }
             read_bq(slot, 2, bfa);
             mma_q(1, bfb);
             mma_q(2, bfa);
@@ -872,15 +900,15 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
             // quarter 2 then covers quarter 2's own reads only)
             constexpr int QM = (NSB + 1) * QC * SG_RB;  // matrix-core instructions of a quarter
             constexpr int QH = QM / (NSB + 1);          // (the first of its NSB + 1 passes)
-            quarter_order(0, QM);
-            __builtin_amdgcn_sched_group_barrier(0x100, QC * NSB, 0);
-            quarter_order(0, QM);
-            quarter_order(0, QH);
-            __builtin_amdgcn_sched_group_barrier(0x100, QC * NSB, 0);
-            quarter_order(QH, QM);
-            quarter_order(0, QM);
+            quarter_order(0, QM, FILL_A{});
+            if constexpr (RK_SG_SGB) __builtin_amdgcn_sched_group_barrier(0x100, QC * NSB, 0);
+            quarter_order(0, QM, FILL_A{});
+            quarter_order(0, QH, FILL_B{});
+            if constexpr (RK_SG_SGB) __builtin_amdgcn_sched_group_barrier(0x100, QC * NSB, 0);
+            quarter_order(QH, QM, FILL_B{});
+            quarter_order(0, QM, FILL_B{});
             sg_pin(pk);
-            __builtin_amdgcn_s_setprio(0);
+            if constexpr (RK_SG_PRIO) __builtin_amdgcn_s_setprio(0);
             if (((int)q & fold_mask) == fold_mask) fold();
             // the waits of the step, behind its matrix-core work: K tile q + 3 and the DMAs issued in L(q - 1) have landed
             // (what L(q) issued stays in flight), this wave's LDS stores of L(q) are done
@@ -1181,6 +1209,10 @@ static bool sg_use_phases() {  // symgemm_ph_kernel (two wave groups half a step
     const char* e = getenv("RK_SYMGEMM_IMPL");
     return e == nullptr || e[0] != 'l';
 }
+static bool sg_force_phases() {  // RK_SYMGEMM_IMPL=ph: the phase kernel for every shape (tests)
+    const char* e = getenv("RK_SYMGEMM_IMPL");
+    return e != nullptr && e[0] == 'p';
+}
 static int sg_tn(int64_t k) { return k <= 128 ? 128 : 256; }
 static size_t sg_image_bytes(int64_t n, int64_t k, int ns) {
     const int64_t npad = round_up(n, SgLayout::W);
@@ -1295,7 +1327,8 @@ static int symm_gemm_impl(const void* Kp, int64_t n, int64_t strip_first, int64_
     if (!bf && rhs_pieces == 1) {
         if (tn == 256) RK_SGPH(8, 1);
         else RK_SGPH(4, 1);
-    } else if (!bf && sg_use_phases()) {
+    } else if (!bf && sg_use_phases() && (tn == 256 || sg_force_phases())) {
+        // (128-column tiles, two pieces: the lockstep kernel is 3 % faster - 43.4 against 44.8 ms at r = 100)
         if (tn == 256) RK_SGPH(8, 2);
         else RK_SGPH(4, 2);
     } else if (bf) {
