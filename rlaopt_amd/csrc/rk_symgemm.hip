@@ -563,6 +563,9 @@ __device__ __forceinline__ void sg_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)"
 #ifndef RK_PH_PROBE
 #define RK_PH_PROBE 0
 #endif
+#ifndef RK_SG_VMEM_FIRST
+#define RK_SG_VMEM_FIRST 0  // phase L: the DMA and the K-tile loads in front of the LDS instructions
+#endif
 #ifndef RK_SG_LATE
 #define RK_SG_LATE 0  // > 0: no vector instructions in the first half of a phase M, this many per matrix-core instruction in the second
 #endif
@@ -610,6 +613,14 @@ struct SgWaitD {
     }
     static constexpr int NA = 2;
 };
+
+#ifndef RK_SG_TRACE
+#define RK_SG_TRACE 0
+#endif
+#if RK_SG_TRACE  // tuning builds only (one piece of V: LDS to spare): cycle stamps of 16 steps of one workgroup (tools/ab_symgemm.py --trace)
+__device__ unsigned long long sg_trace_buf[256];
+constexpr int SG_TRACE_BLOCK = 300, SG_TRACE_Q0 = 100, SG_TRACE_PTS = 6;
+#endif
 
 template <int NCB, int NSB>  // NSB: pieces of V (2, or 1 for a V on the float16 grid: two exact products per pair, half the V bytes)
 __global__ void __launch_bounds__(SG_THREADS, 2)
@@ -838,6 +849,17 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
     using FILL_A = std::integral_constant<int, FILL_Av>;
     using FILL_B = std::integral_constant<int, FILL_Bv>;
 
+#if RK_SG_TRACE
+    unsigned long long* tr = reinterpret_cast<unsigned long long*>(smem + 2 * NS * ABYTES + 4 * BTILE);
+    const bool tracing = NSB == 1 && NCB == 8 && blockIdx.x == SG_TRACE_BLOCK && lane == 0 && (wave & 3) == 0;
+    bool trace_phase = false;
+    auto stamp = [&](int64_t q, int point) {
+        if (tracing && trace_phase && q >= SG_TRACE_Q0 && q < SG_TRACE_Q0 + 16)
+            tr[((q - SG_TRACE_Q0) * SG_TRACE_PTS + point) * 2 + grp] = clock64();
+    };
+#else
+    auto stamp = [&](int64_t, int) {};
+#endif
     if (grp == 1 && !(RK_PH_PROBE & 8)) sg_bar();  // the second group runs one barrier behind the first from here on
 
     auto run_phase = [&](auto load, auto touch, auto jstep, auto waiter, auto split, auto store, auto& s0, auto& s1, auto& s2,
@@ -870,13 +892,21 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
             constexpr int buf = qm & 1, slot = qm;
             const int slot2 = (qm + 2 + grp) & 3;   // the V tile this wave's DMAs fetch: q + 2 (group 0), q + 3 (group 1)
             // ---- L(q): issue only
+            stamp(q, 0);
             if constexpr (RK_SG_PF > 0) touch(at(q + RK_SG_PF));
+            if constexpr (RK_SG_VMEM_FIRST) {
+                dma_b(jstep(at(q + 2 + grp)), slot2);
+                if constexpr (!(RK_PH_PROBE & 16)) load((RK_PH_PROBE & 32) ? (q & 7) : at(q + 4), st_load);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if constexpr (!(RK_PH_PROBE & 4)) store(buf ^ 1, pk);     // K tile q + 1 (own rows)
             read_a(buf);
             read_bq(slot, 0, bfa);
             read_bq(slot, 1, bfb);
-            dma_b(jstep(at(q + 2 + grp)), slot2);
-            if constexpr (!(RK_PH_PROBE & 16)) load((RK_PH_PROBE & 32) ? (q & 7) : at(q + 4), st_load);  // (bit 5: cached tiles)
+            if constexpr (!RK_SG_VMEM_FIRST) {
+                dma_b(jstep(at(q + 2 + grp)), slot2);
+                if constexpr (!(RK_PH_PROBE & 16)) load((RK_PH_PROBE & 32) ? (q & 7) : at(q + 4), st_load);  // (bit 5: cached tiles)
+            }
             if constexpr (RK_SG_SPLIT_IN_L) {  // the split of K tile q + 2 in the wave's idle time in front of the barrier
                 __builtin_amdgcn_sched_barrier(0);
                 pk = split(st_split);
@@ -885,7 +915,13 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
             }
             sg_bar();
             // ---- M(q): quarter 0 | reads of quarter 2 | quarter 1 | part of quarter 2 | reads of quarter 3 | rest
-            if constexpr (RK_SG_PRIO) __builtin_amdgcn_s_setprio(1);
+#if RK_SG_TRACE
+            stamp(q, 1);
+            sg_lgkm0();
+            stamp(q, 2);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if constexpr (RK_SG_PRIO) __builtin_amdgcn_s_setprio(RK_SG_PRIO);
             mma_q(0, bfa);
             if constexpr (!RK_SG_SPLIT_IN_L) {
                 pk = split(st_split);
@@ -913,8 +949,11 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
             // the waits of the step, behind its matrix-core work: K tile q + 3 and the DMAs issued in L(q - 1) have landed
             // (what L(q) issued stays in flight), this wave's LDS stores of L(q) are done
             __builtin_amdgcn_sched_barrier(0);
+            stamp(q, 3);
             Wt::template at<NA + NBQ + (RK_SG_PF > 0 ? 1 : 0)>(st_next);
+            stamp(q, 4);
             sg_lgkm0();
+            stamp(q, 5);
             sg_bar();
         };
         using Q0 = std::integral_constant<int, 0>;
@@ -940,10 +979,20 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
     }
     {
         StageD s0, s1, s2, s3;
+#if RK_SG_TRACE
+        trace_phase = true;
+#endif
         run_phase(load_d, touch_d, jstep_d, SgWaitD{}, split_d, store_d, s0, s1, s2, s3, nD);
         asm volatile("" : "+v"(pfreg));
     }
     if (grp == 0 && !(RK_PH_PROBE & 8)) sg_bar();
+#if RK_SG_TRACE
+    if (NSB == 1 && NCB == 8 && blockIdx.x == SG_TRACE_BLOCK) {
+        sg_lgkm0();
+        sg_bar();
+        if (tid < 16 * SG_TRACE_PTS * 2) sg_trace_buf[tid] = tr[tid];
+    }
+#endif
 
     const int64_t kpad = nct * TN;
 #pragma unroll
@@ -1307,7 +1356,7 @@ static int symm_gemm_impl(const void* Kp, int64_t n, int64_t strip_first, int64_
     } while (0)
 #define RK_SGPH(NCBV, NSBV)                                                                                      \
     do {                                                                                                         \
-        constexpr size_t smem = 2 * 2 * SG_TM * SG_ROWB + 4 * NSBV * 32 * NCBV * SG_ROWB;                        \
+        constexpr size_t smem = 2 * 2 * SG_TM * SG_ROWB + 4 * NSBV * 32 * NCBV * SG_ROWB + (RK_SG_TRACE && NSBV == 1 ? 4096 : 0); \
         static std::atomic<unsigned long long> attr_devs{0};                                                     \
         int dev_ = 0;                                                                                            \
         (void)hipGetDevice(&dev_);                                                                               \
@@ -1354,6 +1403,12 @@ extern "C" int rk_symm_gemm_rhs16(const void* Kp, int64_t n, int64_t strip_first
                                   size_t ws_bytes, void* stream) {
     return symm_gemm_impl(Kp, n, strip_first, strip_stride, kmax, V, k, ldv, alpha, Y, ldy, ws, ws_bytes, stream, 1);
 }
+
+#if RK_SG_TRACE
+extern "C" int rk_debug_symgemm_trace(unsigned long long* out) {  // [step 16][point][group]
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sg_trace_buf), 16 * SG_TRACE_PTS * 2 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // ---- the fused evaluate-and-multiply product (matrix-free operators) -------------------------------------------------
 static size_t kg_x_bytes(int64_t n) {  // |x'|^2 of the padded points + their split images

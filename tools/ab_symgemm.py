@@ -78,27 +78,28 @@ def main():
 
 
 def dump_trace(be):
+    """(a -DRK_SG_TRACE=1 build; the one-piece kernel of the LAST launch: run with --impls rhs16)"""
     import ctypes
 
-    buf = (ctypes.c_ulonglong * 288)()
+    P = 6
+    buf = (ctypes.c_ulonglong * (16 * P * 2))()
     be._lib.rk_debug_symgemm_trace.restype = ctypes.c_int
     be._lib.rk_debug_symgemm_trace.argtypes = [ctypes.c_void_p]
     assert be._lib.rk_debug_symgemm_trace(buf) == 0
-    names = ["M0 start", "M0 operands in", "M0 end", "L1 start", "L1 end", "M1 start", "M1 operands in", "M1 end", "L0 start"]
-    t = [[[buf[(q * 9 + p) * 2 + g] for g in range(2)] for p in range(9)] for q in range(16)]
+    names = ["L start", "M start (barrier passed)", "operands in", "matrix-core work issued", "vmcnt wait done", "lgkmcnt wait done"]
+    t = [[[buf[(q * P + p) * 2 + g] for g in range(2)] for p in range(P)] for q in range(16)]
     t0 = t[0][0][0]
     print("cycle stamps of one workgroup, relative (group 0 | group 1): " + ", ".join(names))
     for q in range(16):
-        print(f"step {q:2d}: " + " ".join(f"{t[q][p][0] - t0:6d}|{t[q][p][1] - t0:6d}" for p in range(9)))
+        print(f"step {q:2d}: " + " ".join(f"{t[q][p][0] - t0:6d}|{t[q][p][1] - t0:6d}" for p in range(P)))
     for g in range(2):
         def mean(f):
             v = [f(q) for q in range(15)]
             return sum(v) / len(v)
-        print(f"group {g}: M0 operand wait {mean(lambda q: t[q][1][g] - t[q][0][g]):.0f}, M0 work {mean(lambda q: t[q][2][g] - t[q][1][g]):.0f}, "
-              f"barrier {mean(lambda q: t[q][3][g] - t[q][2][g]):.0f}, L1 work {mean(lambda q: t[q][4][g] - t[q][3][g]):.0f}, "
-              f"barrier {mean(lambda q: t[q][5][g] - t[q][4][g]):.0f}, M1 operand wait {mean(lambda q: t[q][6][g] - t[q][5][g]):.0f}, "
-              f"M1 work {mean(lambda q: t[q][7][g] - t[q][6][g]):.0f}, barrier (+ fold) {mean(lambda q: t[q][8][g] - t[q][7][g]):.0f}, "
-              f"L0 + barrier {mean(lambda q: t[q + 1][0][g] - t[q][8][g]):.0f}; step {mean(lambda q: t[q + 1][0][g] - t[q][0][g]):.0f}")
+        print(f"group {g}: L issue + barrier wait {mean(lambda q: t[q][1][g] - t[q][0][g]):.0f}, operand wait {mean(lambda q: t[q][2][g] - t[q][1][g]):.0f}, "
+              f"M work {mean(lambda q: t[q][3][g] - t[q][2][g]):.0f}, vmcnt wait {mean(lambda q: t[q][4][g] - t[q][3][g]):.0f}, "
+              f"lgkmcnt wait {mean(lambda q: t[q][5][g] - t[q][4][g]):.0f}, barrier {mean(lambda q: t[q + 1][0][g] - t[q][5][g]):.0f}; "
+              f"step {mean(lambda q: t[q + 1][0][g] - t[q][0][g]):.0f}")
 
 
 if __name__ == "__main__":
