@@ -37,8 +37,8 @@
 //
 // Two kernels:
 //   * symgemm_ph_kernel (default for the float16 split): two phases per step, the two waves of a SIMD half a step apart,
-//     every wait behind the matrix-core work, the V tiles by LDS-DMA - see the comment in front of it.  115 ms at
-//     n = 200 000, r = 512 against 123 - 125 ms for
+//     every wait behind the matrix-core work, the V tiles by LDS-DMA - see the comment in front of it.  104 ms at
+//     n = 200 000, r = 512 against 117 ms on the same box for
 //   * symgemm_kernel (RK_SYMGEMM_IMPL=lockstep, and the three-bfloat16-piece split): two LDS buffers, loads two and three
 //     steps ahead in two register sets, one barrier per step, every wave in the same part of the step at the same time
 //     (with four waves, one per SIMD, the matrix cores were busy 39 % of the time).  Measured on it and not kept (A/B on
@@ -48,7 +48,7 @@
 //     (profiles/r04_symgemm_stagger.log): the stagger that works keeps ONE instruction stream and delays half the waves
 //     by a barrier (symgemm_ph_kernel).
 // A V on the float16 grid (rk_symm_gemm_rhs16: the Gaussian test matrix is drawn on it) has ONE piece: two products per
-// pair, half the V bytes: 89 ms.
+// pair, half the V bytes: 84 ms.
 #include <atomic>
 #include <stdlib.h>
 #include <type_traits>
@@ -528,7 +528,8 @@ symgemm_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char* __
 //     L(q): issue only: LDS store of K tile q + 1 (split in M(q - 1)), operand reads (A, two quarters of B), DMA of a V
 //           tile, loads of K tile q + 4                                                                 | barrier |
 //     M(q): 48 matrix-core instructions; between them the other two quarters of B (into the register sets of the
-//           first two) and the split of K tile q + 2; then the step's two waits                         | barrier |
+//           first two); the split of K tile q + 2 among the last of them (two pieces of V) or spread over all of them
+//           (one piece) - measured, see RK_SG_FILL; then the step's two waits                            | barrier |
 // and waves 4 - 7 pass ONE barrier more before their first step (waves 0 - 3 one more at the end): a SIMD holds one wave
 // of each group, so one is in a phase M while the other is in a phase L.
 //   * V tiles: global_load_lds_dwordx4 (LDS-DMA) straight from the pre-split image into a ring of FOUR LDS slots (tile t
