@@ -560,7 +560,8 @@ __device__ __forceinline__ void sg_bar() {
 __device__ __forceinline__ void sg_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // timing probes (wrong results): RK_PH_PROBE bit 0: no DMA, 1: no matrix-core instructions, 2: no split / LDS store of the K
-// tile, 3: no stagger, 4: no K-tile loads, 5: K-tile loads of the same eight tiles over and over (cache hits)
+// tile, 3: no stagger, 4: no K-tile loads, 5: K-tile loads of the same eight tiles over and over (cache hits), 6: the
+// transposed steps with the direct steps' loads (2 x dwordx4 instead of 8 x dword per thread)
 #ifndef RK_PH_PROBE
 #define RK_PH_PROBE 0
 #endif
@@ -974,8 +975,14 @@ symgemm_ph_kernel(const float* __restrict__ Kp, SgLayout L, const unsigned char*
         Wt::template at<0>(s3);
     };
     {
-        StageT s0, s1, s2, s3;
-        run_phase(load_t, touch_t, jstep_t, SgWaitT{}, split_t, store_t, s0, s1, s2, s3, nT);
+        if constexpr (RK_PH_PROBE & 64) {  // (bit 6: the transposed steps with the direct phase's loads and stores: their cost)
+            StageD s0, s1, s2, s3;
+            auto load_dp = [&](int64_t q, StageD& st) { load_d(nD > 0 ? q % nD : 0, st); };  // (in-bounds addresses only)
+            if (nD > 0) run_phase(load_dp, touch_d, jstep_t, SgWaitD{}, split_d, store_d, s0, s1, s2, s3, nT);
+        } else {
+            StageT s0, s1, s2, s3;
+            run_phase(load_t, touch_t, jstep_t, SgWaitT{}, split_t, store_t, s0, s1, s2, s3, nT);
+        }
         asm volatile("" : "+v"(pfreg));
     }
     {
