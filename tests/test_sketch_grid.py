@@ -57,3 +57,38 @@ def test_packed_operator_passes_the_grid_to_the_sketch_product(monkeypatch):
     Y2 = A @ Om.clone()  # the same values without the tag: the general entry
     assert seen and not any(seen)
     assert torch.allclose(Y, Y2, rtol=1e-5, atol=1e-6)
+
+
+def test_rounded_sketch_preconditions_like_the_unrounded_one(monkeypatch):
+    """Same seed, same draw, entries rounded to the float16 grid or not: the Nystrom spectrum agrees to the rounding level
+    of the test matrix and block PCG takes the same number of iterations to a few percent (a random test matrix rounded to
+    11 bits is as good a test matrix)."""
+    from rlaopt_amd.kernels import RBFLinOp
+    from rlaopt_amd.kernels.configs import KernelConfig
+    from rlaopt_amd.models import LinSys
+    from rlaopt_amd.preconditioners import NystromConfig
+    from rlaopt_amd.solvers import PCGConfig
+
+    dev = torch.device("cpu")
+    g = torch.Generator().manual_seed(3)
+    n, d, r = 1500, 6, 60
+    X = torch.randn(n, d, dtype=torch.float64, generator=g) / d**0.5
+    B = torch.randn(n, 2, dtype=torch.float64, generator=g)
+    reg = 1e-6 * n
+    out = {}
+    for grid in ("1", "0"):
+        monkeypatch.setenv("RK_SKETCH_F16_GRID", grid)
+        torch.manual_seed(11)  # (the sketch seed comes from torch's default generator)
+        A = RBFLinOp(X, X, KernelConfig(const_scaling=1.0, lengthscale=1.0))
+        cfg = PCGConfig(device=dev, max_iters=300, atol=0.0, rtol=1e-9,
+                        precond_config=NystromConfig(rank=r, rho=reg, sketch="gauss"))
+        system = LinSys(A, B, reg=reg)
+        W, log = system.solve(cfg, torch.zeros(n, 2, dtype=torch.float64), callback_freq=1)
+        out[grid] = (max(log), W, system._active_solver.P.S.clone() if hasattr(system, "_active_solver") and hasattr(
+            system._active_solver, "P") and hasattr(system._active_solver.P, "S") else None)
+    it1, W1, S1 = out["1"]
+    it0, W0, S0 = out["0"]
+    assert abs(it1 - it0) <= max(2, 0.03 * it0), (it1, it0)  # (291 and 288 here: two different but equally good test matrices)
+    assert torch.allclose(W1, W0, rtol=1e-5, atol=1e-7)
+    if S1 is not None and S0 is not None:
+        assert float(((S1 - S0).abs() / S0.abs().clamp_min(1e-12)).max()) < 5e-2
