@@ -156,6 +156,17 @@ int rk_kernel_materialize_sympack(int dtype, int store_dtype, int kind, const vo
                                   int64_t ldx, int64_t d, double ell_scalar, const void* ell_vec,
                                   double scale, int64_t strip_first, int64_t strip_stride,
                                   void* Kp, void* stream);
+/* The same packed triangle, float32, written FROM THE MATRIX CORES: d <= 64, kernels smooth in the squared distance (rbf,
+ * matern32, matern52), `center` = a centre for which |(x - c) / ell|^2 <= RK_GRAM_MAX_NORM2 holds over the rows of X
+ * (rk_kernel_center + rk_kernel_gram_bound: the guard of the matrix-free product).  The points are split into two float16
+ * pieces once (workspace), the dot products of a 16 x 16 block are three exact matrix-core products, the kernel function
+ * runs on the accumulators: 4 x the rate of the vector-unit evaluation (the 80 GB triangle of n = 200 000 in ~20 ms: the
+ * speed HBM takes the writes at), entries to the accuracy of the matrix-free product.  Replaces what the reference
+ * re-evaluates in every product (rlaopt/kernels/base.py:43-44). */
+size_t rk_kernel_materialize_sympack_mc_ws_bytes(int64_t n);
+int rk_kernel_materialize_sympack_mc(int kind, const void* X, int64_t n, int64_t ldx, int64_t d, double ell_scalar,
+                                     const void* ell_vec, const void* center, double scale, int64_t strip_first,
+                                     int64_t strip_stride, void* Kp, void* ws, size_t ws_bytes, void* stream);
 size_t rk_symm_matmat_ws_bytes(int dtype, int store_dtype, int64_t n, int64_t k,
                                int64_t strip_first, int64_t strip_stride);
 /* Y (n x k) = alpha * (partial) K V + diag_shift * V */

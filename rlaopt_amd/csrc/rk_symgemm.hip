@@ -1258,6 +1258,103 @@ kgemm_kernel(const unsigned char* __restrict__ ximg1, const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The packed triangle WRITTEN from the matrix cores (float32, d <= 64, kernels smooth in the squared distance).
+//
+// sympack_materialize_kernel (rk_symm.hip) forms the squared distances feature by feature on the vector units: 250 G entries
+// a second whatever the kernel function and whether the float32 operations are packed or not (profiles/r04_materialize.log) -
+// 80 ms for the 80 GB triangle of n = 200 000, 1 TB/s of writes.  Here the entries come as kgemm_kernel evaluates them: the
+// points are centred, scaled, split into two float16 pieces once (the 64-point images of rk_kernelbf16.hip, |x'|^2 <= 32
+// vouched for by the caller's centre), S^T = X_cols X_rows^T by three exact v_mfma_f32_16x16x32_f16 per 16 x 16 block and
+// 32-feature step, the kernel function on the accumulators - element v of a lane is (column 4 (lane / 16) + v, row lane % 16):
+// four consecutive columns of one row, one 16-byte store.  A workgroup keeps the four images of a strip's 256 columns in LDS
+// (64 KiB) and walks up to RI rows of the strip, eight waves x 16 rows at a time.  Entry error: that of the matrix-free
+// product (2^-22 |x'||y'| in the dot product), at the float32 rounding level for |x'|^2 of order 1.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int MC_RI = 1024;  // rows of a strip per workgroup
+template <int KIND>
+__global__ void __launch_bounds__(SG_THREADS, 4)
+sympack_mc_kernel(const unsigned char* __restrict__ ximg, const float* __restrict__ xn, SgLayout L, float w, float kscale,
+                  float* __restrict__ Kp) {
+    constexpr int W = SgLayout::W;
+    constexpr bool RBF = KIND == RK_RBF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* XJ = smem;                                      // [4][KG_IMG]: the strip's 256 points
+    float* NJ = reinterpret_cast<float*>(smem + 4 * KG_IMG);       // their |x'|^2 (RBF: times rbf_c)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int64_t t = blockIdx.y;
+    const int64_t sg = L.first + t * L.stride;                     // global strip
+    const int64_t nrows = (sg + 1) * W < L.n ? (sg + 1) * W : L.n;
+    const int64_t ibeg = (int64_t)blockIdx.x * MC_RI;
+    if (ibeg >= nrows) return;  // (uniform, before any barrier)
+    const int64_t iend = ibeg + MC_RI < nrows ? ibeg + MC_RI : nrows;
+    const float rbf_c = -0.5f * w * w * 1.4426950408889634f;       // exp(-s w^2 / 2) = exp2(rbf_c s)
+    const float m2c = -2.f * rbf_c * KG_UNSCALE;
+    {
+        const sg_u4* src = reinterpret_cast<const sg_u4*>(ximg + sg * 4 * (int64_t)KG_IMG);
+        sg_u4* dst = reinterpret_cast<sg_u4*>(XJ);
+#pragma unroll
+        for (int e = 0; e < 4 * KG_IMG / 16 / SG_THREADS; ++e) dst[tid + SG_THREADS * e] = src[tid + SG_THREADS * e];
+        if (tid < W) NJ[tid] = xn[sg * W + tid] * (RBF ? rbf_c : 1.f);
+    }
+    __syncthreads();
+    float* strip = Kp + L.row_offset(t) * W;
+    for (int64_t i0 = ibeg; i0 < iend; i0 += SG_TM) {
+        const int64_t ip = i0 + 16 * wave + lr;  // (< round_up(n, 256): the image exists)
+        sg_u4 xi[2][2];
+        {
+            const unsigned char* base = ximg + (ip >> 6) * KG_IMG;
+            const int r = (int)(ip & 63);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned char* src = base + kg_chunk(r, 4 * ks + lq);
+                xi[ks][0] = *reinterpret_cast<const sg_u4*>(src);
+                xi[ks][1] = *reinterpret_cast<const sg_u4*>(src + KG_SPLIT);
+            }
+        }
+        const float ni = xn[ip] * (RBF ? rbf_c : 1.f);
+        const bool live = ip < nrows;
+        float* drow = strip + ip * W + 4 * lq;
+#pragma unroll 4
+        for (int jb = 0; jb < 16; ++jb) {
+            sg_acc sj;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sj[v] = 0.f;
+            const unsigned char* img = XJ + (jb >> 2) * KG_IMG;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned char* src = img + kg_chunk(16 * (jb & 3) + lr, 4 * ks + lq);
+                const sg_u4 ah = *reinterpret_cast<const sg_u4*>(src);
+                const sg_u4 am = *reinterpret_cast<const sg_u4*>(src + KG_SPLIT);
+                sj = SgF16::mfma(am, xi[ks][0], sj);
+                sj = SgF16::mfma(ah, xi[ks][1], sj);
+                sj = SgF16::mfma(ah, xi[ks][0], sj);
+            }
+            const float4 nj4 = *reinterpret_cast<const float4*>(NJ + 16 * jb + 4 * lq);
+            const float njv[4] = {nj4.x, nj4.y, nj4.z, nj4.w};
+            float p[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                if constexpr (RBF) {
+                    p[v] = __builtin_amdgcn_exp2f(fmaf(sj[v], m2c, ni + njv[v]));
+                } else {
+                    float s = ni + njv[v] - (2.f * KG_UNSCALE) * sj[v];
+                    s = s > 0.f ? s : 0.f;
+                    p[v] = kernel_value<float>(KIND, s, w);
+                }
+                p[v] = (sg * W + 16 * jb + 4 * lq + v < L.n) ? p[v] * kscale : 0.f;  // (columns past n: zeros, as the vector-unit kernel writes)
+            }
+            if (live) {
+                sg_acc o;
+                o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; o[3] = p[3];
+                __builtin_nontemporal_store(o, reinterpret_cast<sg_acc*>(drow + 16 * jb));
+            }
+        }
+    }
+}
+
 static bool sg_use_bf16x3() {
     const char* e = getenv("RK_SYMGEMM_SPLIT");
     return e != nullptr && (e[0] == 'b' || e[0] == '3');
@@ -1422,6 +1519,71 @@ extern "C" int rk_debug_symgemm_trace(unsigned long long* out) {  // [step 16][p
 static size_t kg_x_bytes(int64_t n) {  // |x'|^2 of the padded points + their split images
     const int64_t npad = round_up(n, 256);
     return (size_t)round_up(npad * (int64_t)sizeof(float), 256) + (size_t)(npad / 64) * KG_IMG;
+}
+
+static size_t mc_ws_bytes(int64_t n) { return 1024 + kg_x_bytes(n); }  // centre / scale vectors + |x'|^2 + split images
+
+extern "C" size_t rk_kernel_materialize_sympack_mc_ws_bytes(int64_t n) { return n > 0 ? mc_ws_bytes(n) : 0; }
+
+extern "C" int rk_kernel_materialize_sympack_mc(int kind, const void* X, int64_t n, int64_t ldx, int64_t d, double ell_scalar,
+                                                const void* ell_vec, const void* center, double scale,
+                                                int64_t strip_first, int64_t strip_stride, void* Kp, void* ws,
+                                                size_t ws_bytes, void* stream) {
+    clear_error();
+    RK_REQUIRE(X && Kp && center, "rk_kernel_materialize_sympack_mc: null pointer (the centre is required)");
+    RK_REQUIRE(kind == RK_RBF || kind == RK_MATERN32 || kind == RK_MATERN52,
+               "rk_kernel_materialize_sympack_mc: kernels smooth in the squared distance only (rbf, matern32, matern52)");
+    RK_REQUIRE(n > 0 && d > 0 && d <= 64 && ldx >= d, "rk_kernel_materialize_sympack_mc: n > 0, 1 <= d <= 64");
+    RK_REQUIRE(strip_stride >= 1 && strip_first >= 0 && strip_first < strip_stride,
+               "rk_kernel_materialize_sympack_mc: bad strip distribution");
+    RK_REQUIRE(ell_vec != nullptr || ell_scalar > 0.0, "rk_kernel_materialize_sympack_mc: lengthscale must be positive");
+    RK_REQUIRE(aligned16(Kp), "rk_kernel_materialize_sympack_mc: output must be 16-byte aligned");
+    const size_t need = mc_ws_bytes(n);
+    if (ws == nullptr || ws_bytes < need || !aligned16(ws)) {
+        set_error("rk_kernel_materialize_sympack_mc: workspace %zu B < required %zu B (16-byte aligned)", ws_bytes, need);
+        return RK_ERR_WORKSPACE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    SgLayout L{n, strip_first, strip_stride};
+    const int64_t T_loc = L.strips_local();
+    if (T_loc == 0) return RK_OK;
+    float* iw = static_cast<float*>(ws);
+    float* muw = iw + 128;
+    const int64_t npad = round_up(n, 256);
+    float* xn = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + 1024);
+    unsigned char* ximg = reinterpret_cast<unsigned char*>(xn) + round_up(npad * (int64_t)sizeof(float), 256);
+    gram_prep_launch((const float*)center, (const float*)ell_vec, d, iw, muw, st);
+    gram_split64_launch((const float*)X, ldx, nullptr, n, npad, d, iw, muw, ximg, xn, st);
+    int rc = launch_status("rk_kernel_materialize_sympack_mc(split)");
+    if (rc != RK_OK) return rc;
+    const int64_t s_last = L.first + (T_loc - 1) * L.stride;
+    const int64_t max_rows = (s_last + 1) * SgLayout::W < n ? (s_last + 1) * SgLayout::W : n;
+    const dim3 grid((unsigned)ceil_div(max_rows, MC_RI), (unsigned)T_loc);
+    const float w = ell_vec ? 1.f : (float)(1.0 / ell_scalar);
+    constexpr size_t smem = 4 * KG_IMG + SgLayout::W * sizeof(float);
+#define RK_MC(KINDV)                                                                                              \
+    do {                                                                                                          \
+        static std::atomic<unsigned long long> attr_devs{0};                                                      \
+        int dev_ = 0;                                                                                             \
+        (void)hipGetDevice(&dev_);                                                                                \
+        const unsigned long long bit_ = 1ull << (dev_ & 63);                                                      \
+        if (!(attr_devs.load(std::memory_order_acquire) & bit_)) {                                                \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(sympack_mc_kernel<KINDV>),                      \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {       \
+                (void)hipGetLastError();                                                                          \
+                set_error("rk_kernel_materialize_sympack_mc: cannot reserve %zu bytes of LDS", smem);             \
+                return RK_ERR_LAUNCH;                                                                             \
+            }                                                                                                     \
+            attr_devs.fetch_or(bit_, std::memory_order_release);                                                  \
+        }                                                                                                         \
+        hipLaunchKernelGGL((sympack_mc_kernel<KINDV>), grid, dim3(SG_THREADS), smem, st, ximg, xn, L, w,          \
+                           (float)scale, (float*)Kp);                                                             \
+    } while (0)
+    if (kind == RK_RBF) RK_MC(RK_RBF);
+    else if (kind == RK_MATERN32) RK_MC(RK_MATERN32);
+    else RK_MC(RK_MATERN52);
+#undef RK_MC
+    return launch_status("rk_kernel_materialize_sympack_mc");
 }
 
 extern "C" size_t rk_kernel_sketch_ws_bytes(int64_t n1, int64_t n2, int64_t k) {

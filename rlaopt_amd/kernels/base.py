@@ -299,7 +299,7 @@ class _KernelBlock:
         out = None
         for f in range(parts):
             Kp = be.sympack_materialize(self.kind, self.A1, self.config.lengthscale, scale=self.scale, first=f,
-                                        stride=parts, out=buf)
+                                        stride=parts, out=buf, gram_center=self.gram_center)
             for c0 in range(0, xs.shape[1], 1024):
                 part = be.symm_gemm(Kp, n, xs[:, c0 : c0 + 1024], kmax=abs(self.scale), first=f, stride=parts,
                                     tag="kernel_sketch_product", rhs_f16=grid)

@@ -206,7 +206,11 @@ class HipBackend:
                 _dt(X), _ptr(X), X.shape[0], ld, d, ell, _ptr(ell_vec), _ptr(center), _ptr(bound), _stream(dev)
             )
             _lib.check(rc, "rk_kernel_gram_bound")
-        return center if float(bound) <= _lib.GRAM_MAX_NORM2 else None
+        b = float(bound)
+        if b > _lib.GRAM_MAX_NORM2:
+            return None
+        center._rk_norm2 = b  # (max |(x - c) / ell|^2 found: consumers with a tighter budget read it)
+        return center
 
     def kernel_matmat(self, kind, X1, X2, lengthscale, V, scale=1.0, idx1=None, idx2=None,
                       gram_center="auto", x2_cache=None):
@@ -301,10 +305,15 @@ class HipBackend:
     def sympack_elems(self, n, first=0, stride=1, store_dtype=torch.float32):
         return int(self._lib.rk_sympack_elems(_DT[store_dtype], n, first, stride))
 
-    def sympack_materialize(self, kind, X, lengthscale, scale=1.0, first=0, stride=1, store_dtype=None, out=None):
+    def sympack_materialize(self, kind, X, lengthscale, scale=1.0, first=0, stride=1, store_dtype=None, out=None,
+                            gram_center="auto"):
         """Strip-packed upper triangle of scale * K(X, X) (strips first, first+stride, ...).
         ``store_dtype=torch.float32`` with float64 X keeps the entries in float32.  ``out``: a 1-D buffer of the
-        storage dtype with at least ``sympack_elems`` entries to write into (its head is returned)."""
+        storage dtype with at least ``sympack_elems`` entries to write into (its head is returned).
+        float32, d <= 64, rbf / matern32 / matern52 and a centre within the norm bound (``gram_center``: the tensor
+        :meth:`gram_center` returned for X, None = do not, "auto" = compute it here): the entries are evaluated on
+        the matrix cores (``rk_kernel_materialize_sympack_mc``) when max |(x - c) / ell|^2 <= RK_SYMPACK_MC_NORM2 (8);
+        RK_SYMPACK_MC=0 keeps the vector-unit kernel."""
         dev, kid, X, ld, _X2, _ld2, ell, ell_vec, _i1, _i2, n, _n2 = self._kernel_common(
             kind, X, X, lengthscale, None, None
         )
@@ -318,6 +327,23 @@ class HipBackend:
             Kp = out[: max(elems, 1)]
         else:
             Kp = torch.empty(max(elems, 1), dtype=store_dtype, device=dev)
+        if (X.dtype == torch.float32 and store_dtype == torch.float32 and X.shape[1] <= 64 and kind in ("rbf", "matern32", "matern52")
+                and gram_center is not None and float(scale) != 0.0 and os.environ.get("RK_SYMPACK_MC", "1") != "0"):
+            gc = self.gram_center(X, X, lengthscale) if isinstance(gram_center, str) else gram_center
+            # entry error of this evaluation: 2^-22 |x'||y'| in the dot product, i.e. up to ~7e-7 max|x'|^2 relative to the
+            # kernel's scale: taken for STORED entries only while that stays near float32's own rounding
+            lim = float(os.environ.get("RK_SYMPACK_MC_NORM2", "8"))
+            if gc is not None and getattr(gc, "_rk_norm2", lim) <= lim:
+                _req(gc)
+                gc = gc.contiguous()
+                nbytes = self._lib.rk_kernel_materialize_sympack_mc_ws_bytes(n)
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                rc = self._lib.rk_kernel_materialize_sympack_mc(
+                    kid, _ptr(X), n, ld, X.shape[1], ell, _ptr(ell_vec), _ptr(gc), float(scale), first, stride, _ptr(Kp),
+                    _ptr(ws), nbytes, _stream(dev),
+                )
+                _lib.check(rc, "rk_kernel_materialize_sympack_mc")
+                return Kp
         rc = self._lib.rk_kernel_materialize_sympack(
             _dt(X), _DT[store_dtype], kid, _ptr(X), n, ld, X.shape[1], ell, _ptr(ell_vec),
             float(scale), first, stride, _ptr(Kp), _stream(dev),

@@ -28,7 +28,8 @@ class OracleBackend:
         return ok.kernel_matmat(kind, X1, X2, lengthscale, V, scale, idx1=idx1, idx2=idx2)
 
     # sympack stand-in: keeps the dense matrix restricted to this rank's strips (upper part)
-    def sympack_materialize(self, kind, X, lengthscale, scale=1.0, first=0, stride=1, store_dtype=None):
+    def sympack_materialize(self, kind, X, lengthscale, scale=1.0, first=0, stride=1, store_dtype=None, out=None,
+                            gram_center=None):
         n = X.shape[0]
         store_dtype = store_dtype or X.dtype
         W = 256 if store_dtype == torch.float32 else 128

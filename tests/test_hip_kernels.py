@@ -261,6 +261,60 @@ def test_sympack_product_matches_dense(be, prec, kind, n, k):
     assert rel_err(be.symm_matmat(Kp, n, Vd).cpu(), want) < LIM[dt] * 5
 
 
+@pytest.mark.parametrize("kind", ["rbf", "matern32", "matern52"])
+@pytest.mark.parametrize("n,d,stride,ard", [(1, 3, 1, False), (255, 9, 1, False), (256, 64, 2, True), (257, 33, 1, False),
+                                          (1300, 50, 3, False), (4097, 64, 1, True), (5000, 7, 5, False)])
+def test_sympack_written_from_the_matrix_cores_matches_the_vector_unit_kernel(be, monkeypatch, kind, n, d, stride, ard):
+    """rk_kernel_materialize_sympack_mc: the packed triangle evaluated on the matrix cores (split points, three exact
+    products per block, the kernel function on the accumulators) against the vector-unit kernel entry by entry (same
+    layout, same zeros past column n) and against the float64 oracle; every strip distribution; data with a common
+    offset (the centre removes it); reproducible bit for bit; off-bound data and RK_SYMPACK_MC=0 take the old kernel."""
+    dt = torch.float32
+    g = torch.Generator().manual_seed(3 * n + d)
+    X = torch.randn(n, d, dtype=dt, generator=g) / d**0.5 + 2.0
+    ell = (0.7 + 0.6 * torch.rand(d, dtype=dt, generator=g)) if ard else 0.9
+    Xd = X.to(dev())
+    elld = ell.to(dev()) if ard else ell
+    gc = be.gram_center(Xd, Xd, elld)
+    assert gc is not None
+    monkeypatch.setenv("RK_SYMPACK_MC_NORM2", "32")  # (every data set inside the norm bound, whatever its spread)
+    # entry error: 2^-22 |x'||y'| in the dot product -> ~7e-7 max|x'|^2 of the kernel's scale, + float32 rounding
+    tol = (7e-7 * gc._rk_norm2 + 1e-6) * 1.7
+    Kd = ok.kernel_matrix(kind, X.double(), X.double(), ell.double() if ard else ell, 1.7)
+    for first in range(stride):
+        if be.sympack_elems(n, first, stride) == 0:
+            continue  # (this rank holds no strip)
+        new = be.sympack_materialize(kind, Xd, elld, scale=1.7, first=first, stride=stride, gram_center=gc)
+        assert torch.equal(new, be.sympack_materialize(kind, Xd, elld, scale=1.7, first=first, stride=stride))  # ("auto")
+        monkeypatch.setenv("RK_SYMPACK_MC", "0")
+        old = be.sympack_materialize(kind, Xd, elld, scale=1.7, first=first, stride=stride)
+        monkeypatch.delenv("RK_SYMPACK_MC")
+        assert new.shape == old.shape
+        assert torch.equal(new == 0, old == 0) or float((new - old).abs().max()) < 1e-5  # (the zero padding sits in the same places)
+        assert float((new - old).abs().max()) < tol, (first, float((new - old).abs().max()), gc._rk_norm2)
+        # against the float64 matrix, strip by strip
+        off = 0
+        for s in range(first, -(-n // 256), stride):
+            rows, lo, hi = min(n, (s + 1) * 256), s * 256, min(n, (s + 1) * 256)
+            blk = new[off : off + rows * 256].view(rows, 256).cpu().double()
+            assert float((blk[:, : hi - lo] - Kd[:rows, lo:hi]).abs().max()) < tol
+            assert float(blk[:, hi - lo :].abs().max()) == 0.0 if hi - lo < 256 else True
+            off += rows * 256
+    # data outside the norm bound: no centre, the vector-unit kernel
+    if n >= 255:
+        far = Xd * 40.0
+        assert be.gram_center(far, far, 0.9) is None
+        Kp = be.sympack_materialize(kind, far, 0.9)
+        mid = Xd * 4.0  # inside the bound of the matrix-free product, outside the budget for stored entries
+        gm = be.gram_center(mid, mid, 0.9)
+        monkeypatch.setenv("RK_SYMPACK_MC_NORM2", "8")
+        Km = be.sympack_materialize(kind, mid, 0.9) if gm is not None and gm._rk_norm2 > 8 else None
+        monkeypatch.setenv("RK_SYMPACK_MC", "0")
+        assert torch.equal(Kp, be.sympack_materialize(kind, far, 0.9))
+        if Km is not None:
+            assert torch.equal(Km, be.sympack_materialize(kind, mid, 0.9))
+
+
 @pytest.mark.parametrize("n", [1, 255, 4097, 300000])
 @pytest.mark.parametrize("k1,k2", [(1, 1), (2, 3), (4, 4), (3, 1)])
 def test_gram_small_block_inner_products(be, prec, n, k1, k2):
