@@ -164,9 +164,18 @@ int rk_kernel_materialize_sympack(int dtype, int store_dtype, int kind, const vo
  * speed HBM takes the writes at), entries to the accuracy of the matrix-free product.  Replaces what the reference
  * re-evaluates in every product (rlaopt/kernels/base.py:43-44). */
 size_t rk_kernel_materialize_sympack_mc_ws_bytes(int64_t n);
+
 int rk_kernel_materialize_sympack_mc(int kind, const void* X, int64_t n, int64_t ldx, int64_t d, double ell_scalar,
                                      const void* ell_vec, const void* center, double scale, int64_t strip_first,
                                      int64_t strip_stride, void* Kp, void* ws, size_t ws_bytes, void* stream);
+/* The dense row-major block of rk_kernel_materialize (float32, d <= 64, rbf / matern32 / matern52, a centre within the norm
+ * bound) evaluated the same way: K(X1[idx1], X2[idx2]) - the |blk| x |blk| blocks of a sketch-and-project step
+ * (rlaopt/solvers/sap.py:64-66) and row-major shards. */
+size_t rk_kernel_materialize_mc_ws_bytes(int64_t n1, int64_t n2);
+int rk_kernel_materialize_mc(int kind, const void* X1, int64_t n1, int64_t ldx1, const int64_t* idx1, const void* X2,
+                             int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d, double ell_scalar,
+                             const void* ell_vec, const void* center, double scale, void* K, int64_t ldk, void* ws,
+                             size_t ws_bytes, void* stream);
 size_t rk_symm_matmat_ws_bytes(int dtype, int store_dtype, int64_t n, int64_t k,
                                int64_t strip_first, int64_t strip_stride);
 /* Y (n x k) = alpha * (partial) K V + diag_shift * V */

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("RK_HIP_LIBRARY") or os.path.join(_HERE, "librk_hip.so
 RK_F32, RK_F64 = 0, 1
 GRAM_MAX_NORM2 = 32.0  # RK_GRAM_MAX_NORM2 of include/rk.h
 KIND_IDS = {"rbf": 0, "laplace": 1, "matern12": 2, "matern32": 3, "matern52": 4}
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 # name -> (restype, argtypes); must list every symbol declared in include/rk.h
 SIGNATURES = {
@@ -70,6 +70,12 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64, c_int64, c_double, c_double, c_void_p,
          c_int64, c_void_p, c_size_t, c_void_p],
+    ),
+    "rk_kernel_materialize_mc_ws_bytes": (c_size_t, [c_int64, c_int64]),
+    "rk_kernel_materialize_mc": (
+        c_int,
+        [c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_double, c_void_p,
+         c_void_p, c_double, c_void_p, c_int64, c_void_p, c_size_t, c_void_p],
     ),
     "rk_kernel_materialize_sympack_mc_ws_bytes": (c_size_t, [c_int64]),
     "rk_kernel_materialize_sympack_mc": (

@@ -20,7 +20,7 @@ void clear_error() { g_err[0] = '\0'; }
 }  // namespace rk
 
 extern "C" const char* rk_last_error(void) { return rk::g_err; }
-extern "C" int rk_abi_version(void) { return 22; }
+extern "C" int rk_abi_version(void) { return 23; }
 
 // ---- wire buffer of the reduce-scatter that sums the ranks' partial products (rlaopt_amd/dist.py) ----------
 namespace rk {

@@ -1355,6 +1355,96 @@ sympack_mc_kernel(const unsigned char* __restrict__ ximg, const float* __restric
     }
 }
 
+// The same evaluation into a ROW-MAJOR block K (n1 x n2, leading dimension ldk): K(X1[idx1], X2[idx2]) for the ASkotch
+// blocks (rlaopt/solvers/sap.py:64-66) and row-major shards.  A workgroup keeps 256 points of X2 in LDS and walks `ri`
+// rows of X1.  16-byte stores where the row alignment allows, element stores otherwise (and at the ragged edge).
+template <int KIND>
+__global__ void __launch_bounds__(SG_THREADS, 4)
+kmat_mc_kernel(const unsigned char* __restrict__ ximg1, const float* __restrict__ xn1, int64_t n1,
+               const unsigned char* __restrict__ ximg2, const float* __restrict__ xn2, int64_t n2, float w, float kscale,
+               float* __restrict__ K, int64_t ldk, int64_t ri, int vec_ok) {
+    constexpr int W = 256;
+    constexpr bool RBF = KIND == RK_RBF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* XJ = smem;
+    float* NJ = reinterpret_cast<float*>(smem + 4 * KG_IMG);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int64_t cg = blockIdx.y;
+    const int64_t ibeg = (int64_t)blockIdx.x * ri;
+    if (ibeg >= n1) return;  // (uniform, before any barrier)
+    const int64_t iend = ibeg + ri < n1 ? ibeg + ri : n1;
+    const float rbf_c = -0.5f * w * w * 1.4426950408889634f;
+    const float m2c = -2.f * rbf_c * KG_UNSCALE;
+    {
+        const sg_u4* src = reinterpret_cast<const sg_u4*>(ximg2 + cg * 4 * (int64_t)KG_IMG);
+        sg_u4* dst = reinterpret_cast<sg_u4*>(XJ);
+#pragma unroll
+        for (int e = 0; e < 4 * KG_IMG / 16 / SG_THREADS; ++e) dst[tid + SG_THREADS * e] = src[tid + SG_THREADS * e];
+        if (tid < W) NJ[tid] = xn2[cg * W + tid] * (RBF ? rbf_c : 1.f);
+    }
+    __syncthreads();
+    for (int64_t i0 = ibeg; i0 < iend; i0 += SG_TM) {
+        const int64_t ip = i0 + 16 * wave + lr;  // (< round_up(n1, 256): the image exists)
+        sg_u4 xi[2][2];
+        {
+            const unsigned char* base = ximg1 + (ip >> 6) * KG_IMG;
+            const int r = (int)(ip & 63);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned char* src = base + kg_chunk(r, 4 * ks + lq);
+                xi[ks][0] = *reinterpret_cast<const sg_u4*>(src);
+                xi[ks][1] = *reinterpret_cast<const sg_u4*>(src + KG_SPLIT);
+            }
+        }
+        const float ni = xn1[ip] * (RBF ? rbf_c : 1.f);
+        const bool live = ip < n1;
+        float* drow = K + ip * ldk + cg * W + 4 * lq;
+#pragma unroll 4
+        for (int jb = 0; jb < 16; ++jb) {
+            sg_acc sj;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sj[v] = 0.f;
+            const unsigned char* img = XJ + (jb >> 2) * KG_IMG;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned char* src = img + kg_chunk(16 * (jb & 3) + lr, 4 * ks + lq);
+                const sg_u4 ah = *reinterpret_cast<const sg_u4*>(src);
+                const sg_u4 am = *reinterpret_cast<const sg_u4*>(src + KG_SPLIT);
+                sj = SgF16::mfma(am, xi[ks][0], sj);
+                sj = SgF16::mfma(ah, xi[ks][1], sj);
+                sj = SgF16::mfma(ah, xi[ks][0], sj);
+            }
+            const float4 nj4 = *reinterpret_cast<const float4*>(NJ + 16 * jb + 4 * lq);
+            const float njv[4] = {nj4.x, nj4.y, nj4.z, nj4.w};
+            sg_acc o;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float pv;
+                if constexpr (RBF) {
+                    pv = __builtin_amdgcn_exp2f(fmaf(sj[v], m2c, ni + njv[v]));
+                } else {
+                    float s = ni + njv[v] - (2.f * KG_UNSCALE) * sj[v];
+                    s = s > 0.f ? s : 0.f;
+                    pv = kernel_value<float>(KIND, s, w);
+                }
+                o[v] = pv * kscale;
+            }
+            const int64_t j = cg * W + 16 * jb + 4 * lq;
+            if (live) {
+                if (vec_ok && j + 3 < n2) {
+                    __builtin_nontemporal_store(o, reinterpret_cast<sg_acc*>(drow + 16 * jb));
+                } else {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (j + v < n2) drow[16 * jb + v] = o[v];
+                }
+            }
+        }
+    }
+}
+
 static bool sg_use_bf16x3() {
     const char* e = getenv("RK_SYMGEMM_SPLIT");
     return e != nullptr && (e[0] == 'b' || e[0] == '3');
@@ -1584,6 +1674,74 @@ extern "C" int rk_kernel_materialize_sympack_mc(int kind, const void* X, int64_t
     else RK_MC(RK_MATERN52);
 #undef RK_MC
     return launch_status("rk_kernel_materialize_sympack_mc");
+}
+
+extern "C" size_t rk_kernel_materialize_mc_ws_bytes(int64_t n1, int64_t n2) {
+    return (n1 > 0 && n2 > 0) ? 1024 + kg_x_bytes(n1) + kg_x_bytes(n2) : 0;
+}
+
+extern "C" int rk_kernel_materialize_mc(int kind, const void* X1, int64_t n1, int64_t ldx1, const int64_t* idx1, const void* X2,
+                                        int64_t n2, int64_t ldx2, const int64_t* idx2, int64_t d, double ell_scalar,
+                                        const void* ell_vec, const void* center, double scale, void* K, int64_t ldk,
+                                        void* ws, size_t ws_bytes, void* stream) {
+    clear_error();
+    RK_REQUIRE(X1 && X2 && K && center, "rk_kernel_materialize_mc: null pointer (the centre is required)");
+    RK_REQUIRE(kind == RK_RBF || kind == RK_MATERN32 || kind == RK_MATERN52,
+               "rk_kernel_materialize_mc: kernels smooth in the squared distance only (rbf, matern32, matern52)");
+    RK_REQUIRE(n1 > 0 && n2 > 0 && d > 0 && d <= 64 && ldx1 >= d && ldx2 >= d && ldk >= n2,
+               "rk_kernel_materialize_mc: bad sizes (n1=%lld n2=%lld d=%lld ldk=%lld)", (long long)n1, (long long)n2,
+               (long long)d, (long long)ldk);
+    RK_REQUIRE(ell_vec != nullptr || ell_scalar > 0.0, "rk_kernel_materialize_mc: lengthscale must be positive");
+    const size_t need = rk_kernel_materialize_mc_ws_bytes(n1, n2);
+    if (ws == nullptr || ws_bytes < need || !aligned16(ws)) {
+        set_error("rk_kernel_materialize_mc: workspace %zu B < required %zu B (16-byte aligned)", ws_bytes, need);
+        return RK_ERR_WORKSPACE;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* iw = static_cast<float*>(ws);
+    float* muw = iw + 128;
+    const bool same = X1 == X2 && idx1 == idx2 && n1 == n2 && ldx1 == ldx2;
+    const int64_t n1pad = round_up(n1, 256), n2pad = round_up(n2, 256);
+    float* xn1 = reinterpret_cast<float*>(static_cast<unsigned char*>(ws) + 1024);
+    unsigned char* ximg1 = reinterpret_cast<unsigned char*>(xn1) + round_up(n1pad * (int64_t)sizeof(float), 256);
+    float* xn2 = same ? xn1 : reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(xn1) + kg_x_bytes(n1));
+    unsigned char* ximg2 = same ? ximg1 : reinterpret_cast<unsigned char*>(xn2) + round_up(n2pad * (int64_t)sizeof(float), 256);
+    gram_prep_launch((const float*)center, (const float*)ell_vec, d, iw, muw, st);
+    gram_split64_launch((const float*)X1, ldx1, idx1, n1, n1pad, d, iw, muw, ximg1, xn1, st);
+    if (!same) gram_split64_launch((const float*)X2, ldx2, idx2, n2, n2pad, d, iw, muw, ximg2, xn2, st);
+    int rc = launch_status("rk_kernel_materialize_mc(split)");
+    if (rc != RK_OK) return rc;
+    // rows per workgroup: 1024, fewer for small blocks (at least ~1 000 workgroups in the grid)
+    const int64_t cgs = ceil_div(n2, 256);
+    int64_t ri = 1024;
+    while (ri > 128 && ceil_div(n1, ri) * cgs < 1024) ri /= 2;
+    const dim3 grid((unsigned)ceil_div(n1, ri), (unsigned)cgs);
+    const float w = ell_vec ? 1.f : (float)(1.0 / ell_scalar);
+    const int vec_ok = (ldk % 4 == 0) && aligned16(K);
+    constexpr size_t smem = 4 * KG_IMG + 256 * sizeof(float);
+#define RK_MC(KINDV)                                                                                              \
+    do {                                                                                                          \
+        static std::atomic<unsigned long long> attr_devs{0};                                                      \
+        int dev_ = 0;                                                                                             \
+        (void)hipGetDevice(&dev_);                                                                                \
+        const unsigned long long bit_ = 1ull << (dev_ & 63);                                                      \
+        if (!(attr_devs.load(std::memory_order_acquire) & bit_)) {                                                \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kmat_mc_kernel<KINDV>),                         \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {       \
+                (void)hipGetLastError();                                                                          \
+                set_error("rk_kernel_materialize_mc: cannot reserve %zu bytes of LDS", smem);                     \
+                return RK_ERR_LAUNCH;                                                                             \
+            }                                                                                                     \
+            attr_devs.fetch_or(bit_, std::memory_order_release);                                                  \
+        }                                                                                                         \
+        hipLaunchKernelGGL((kmat_mc_kernel<KINDV>), grid, dim3(SG_THREADS), smem, st, ximg1, xn1, n1, ximg2, xn2, \
+                           n2, w, (float)scale, (float*)K, ldk, ri, vec_ok);                                      \
+    } while (0)
+    if (kind == RK_RBF) RK_MC(RK_RBF);
+    else if (kind == RK_MATERN32) RK_MC(RK_MATERN32);
+    else RK_MC(RK_MATERN52);
+#undef RK_MC
+    return launch_status("rk_kernel_materialize_mc");
 }
 
 extern "C" size_t rk_kernel_sketch_ws_bytes(int64_t n1, int64_t n2, int64_t k) {

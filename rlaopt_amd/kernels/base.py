@@ -805,7 +805,8 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
             cfg = self._kernel_config_devices[dev]
             Ab = self._A1[blk.to(self._A1.device)].to(dev)
             A2b = Ab if _same_points(self._A1, self._A2) else self._A2[blk.to(self._A2.device)].to(dev)
-            Kb = be.kernel_materialize(self._kind, Ab, A2b, cfg.lengthscale, scale=self._scaling)
+            Kb = be.kernel_materialize(self._kind, Ab, A2b, cfg.lengthscale, scale=self._scaling,
+                                       gram_center=self._gram_center_on(dev))
 
             def full_matvec(x, Kb=Kb):
                 return be.matmat(Kb, x)
@@ -831,7 +832,8 @@ class _DistributedKernelLinOp(_DistributedTwoSidedLinOp, ScaleMixin):
                 # a block this small is written out once (|blk|^2 pair evaluations) and every
                 # later product streams it: one SAP step multiplies with K_bb ~17 times (7 sketch
                 # passes of 16 columns, <= 10 power iterations) - measured 2 ms of a 17 ms step
-                Kb = be.kernel_materialize(self._kind, A1c, A2b, cfg.lengthscale, scale=self._scaling)
+                Kb = be.kernel_materialize(self._kind, A1c, A2b, cfg.lengthscale, scale=self._scaling,
+                                           gram_center=self._gram_center_on(dev))
                 dense[i] = Kb
 
                 def matvec(x, Kb=Kb):

@@ -165,12 +165,29 @@ class HipBackend:
         n2 = X2.shape[0] if idx2 is None else idx2.numel()
         return dev, _lib.KIND_IDS[kind], X1, ld1, X2, ld2, ell, ell_vec, idx1, idx2, n1, n2
 
-    def kernel_materialize(self, kind, X1, X2, lengthscale, scale=1.0, idx1=None, idx2=None, out=None):
+    def kernel_materialize(self, kind, X1, X2, lengthscale, scale=1.0, idx1=None, idx2=None, out=None, gram_center=None):
+        """Dense row-major block scale * K(X1[idx1], X2[idx2]).  ``gram_center``: the tensor :meth:`gram_center` returned for
+        point sets that contain these (float32, d <= 64, rbf / matern32 / matern52, within the norm budget of stored
+        entries): the block is evaluated on the matrix cores (``rk_kernel_materialize_mc``)."""
         dev, kid, X1, ld1, X2, ld2, ell, ell_vec, idx1, idx2, n1, n2 = self._kernel_common(
             kind, X1, X2, lengthscale, idx1, idx2
         )
         if out is None:
             out = torch.empty((n1, n2), dtype=X1.dtype, device=dev)
+        if (gram_center is not None and X1.dtype == torch.float32 and X1.shape[1] <= 64 and kind in ("rbf", "matern32", "matern52")
+                and n1 > 0 and n2 > 0 and out.dtype == torch.float32 and out.stride(1) == 1 and float(scale) != 0.0
+                and os.environ.get("RK_SYMPACK_MC", "1") != "0"
+                and getattr(gram_center, "_rk_norm2", float("inf")) <= float(os.environ.get("RK_SYMPACK_MC_NORM2", "8"))):
+            _req(gram_center)
+            gc = gram_center.contiguous()
+            nbytes = self._lib.rk_kernel_materialize_mc_ws_bytes(n1, n2)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            rc = self._lib.rk_kernel_materialize_mc(
+                kid, _ptr(X1), n1, ld1, _ptr(idx1), _ptr(X2), n2, ld2, _ptr(idx2), X1.shape[1], ell, _ptr(ell_vec), _ptr(gc),
+                float(scale), _ptr(out), out.stride(0), _ptr(ws), nbytes, _stream(dev),
+            )
+            _lib.check(rc, "rk_kernel_materialize_mc")
+            return out
         rc = self._lib.rk_kernel_materialize(
             _dt(X1), kid, _ptr(X1), n1, ld1, _ptr(idx1), _ptr(X2), n2, ld2, _ptr(idx2),
             X1.shape[1], ell, _ptr(ell_vec), float(scale), _ptr(out), out.stride(0), _stream(dev),
@@ -333,7 +350,7 @@ class HipBackend:
             # entry error of this evaluation: 2^-22 |x'||y'| in the dot product, i.e. up to ~7e-7 max|x'|^2 relative to the
             # kernel's scale: taken for STORED entries only while that stays near float32's own rounding
             lim = float(os.environ.get("RK_SYMPACK_MC_NORM2", "8"))
-            if gc is not None and getattr(gc, "_rk_norm2", lim) <= lim:
+            if gc is not None and getattr(gc, "_rk_norm2", float("inf")) <= lim:
                 _req(gc)
                 gc = gc.contiguous()
                 nbytes = self._lib.rk_kernel_materialize_sympack_mc_ws_bytes(n)

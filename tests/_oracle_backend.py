@@ -18,7 +18,7 @@ def _two_d(v):
 class OracleBackend:
     name = "oracle-cpu"
 
-    def kernel_materialize(self, kind, X1, X2, lengthscale, scale=1.0, idx1=None, idx2=None, out=None):
+    def kernel_materialize(self, kind, X1, X2, lengthscale, scale=1.0, idx1=None, idx2=None, out=None, gram_center=None):
         A1 = X1 if idx1 is None else X1[idx1]
         A2 = X2 if idx2 is None else X2[idx2]
         return ok.kernel_matrix(kind, A1, A2, lengthscale, scale)

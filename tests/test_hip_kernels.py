@@ -315,6 +315,49 @@ def test_sympack_written_from_the_matrix_cores_matches_the_vector_unit_kernel(be
             assert torch.equal(Km, be.sympack_materialize(kind, mid, 0.9))
 
 
+@pytest.mark.parametrize("kind", ["rbf", "matern32", "matern52"])
+@pytest.mark.parametrize("n1,n2,d,gather,ard", [(1, 1, 3, False, False), (300, 300, 9, False, True), (5000, 5000, 50, True, False),
+                                                (777, 1301, 33, False, False), (1500, 515, 64, True, True), (129, 2051, 5, True, False)])
+def test_row_major_block_written_from_the_matrix_cores(be, monkeypatch, kind, n1, n2, d, gather, ard):
+    """rk_kernel_materialize_mc: the dense row-major block evaluated on the matrix cores (the ASkotch blocks K(X[blk], X[blk]),
+    row-major shards) against the vector-unit kernel and the float64 oracle: square and rectangular, gathered rows, widths
+    that are not multiples of 4 (element stores) and views with a wider leading dimension."""
+    dt = torch.float32
+    g = torch.Generator().manual_seed(n1 + 7 * n2 + d)
+    N = max(n1, n2) * (3 if gather else 1)
+    X = torch.randn(N, d, dtype=dt, generator=g) / d**0.5 - 1.5
+    ell = (0.7 + 0.6 * torch.rand(d, dtype=dt, generator=g)) if ard else 1.1
+    Xd = X.to(dev())
+    elld = ell.to(dev()) if ard else ell
+    gc = be.gram_center(Xd, Xd, elld)
+    assert gc is not None
+    monkeypatch.setenv("RK_SYMPACK_MC_NORM2", "32")
+    tol = (7e-7 * gc._rk_norm2 + 1e-6) * 0.6
+    if gather:
+        i1 = torch.randperm(N, generator=g)[:n1]
+        i2 = i1 if n1 == n2 else torch.randperm(N, generator=g)[:n2]
+        X1, X2 = Xd, Xd
+        new = be.kernel_materialize(kind, Xd, Xd, elld, scale=0.6, idx1=i1.to(dev()), idx2=i2.to(dev()), gram_center=gc)
+        old = be.kernel_materialize(kind, Xd, Xd, elld, scale=0.6, idx1=i1.to(dev()), idx2=i2.to(dev()))
+        want = ok.kernel_matrix(kind, X[i1].double(), X[i2].double(), ell.double() if ard else ell, 0.6)
+    else:
+        X1, X2 = Xd[:n1], (Xd[:n2] if n1 == n2 else Xd[N - n2 :])
+        new = be.kernel_materialize(kind, X1, X2, elld, scale=0.6, gram_center=gc)
+        old = be.kernel_materialize(kind, X1, X2, elld, scale=0.6)
+        want = ok.kernel_matrix(kind, X1.cpu().double(), X2.cpu().double(), ell.double() if ard else ell, 0.6)
+    assert new.shape == (n1, n2)
+    assert float((new - old).abs().max()) < tol, float((new - old).abs().max())
+    assert float((new.cpu().double() - want).abs().max()) < tol
+    assert torch.equal(new, be.kernel_materialize(kind, X1, X2, elld, scale=0.6, gram_center=gc,
+                                                   **({"idx1": i1.to(dev()), "idx2": i2.to(dev())} if gather else {})))
+    # into a view with a wider leading dimension; the columns beside it stay untouched
+    wide = torch.full((n1, n2 + 5), 7.0, dtype=dt, device=dev())
+    be.kernel_materialize(kind, X1, X2, elld, scale=0.6, gram_center=gc, out=wide[:, 2 : 2 + n2],
+                          **({"idx1": i1.to(dev()), "idx2": i2.to(dev())} if gather else {}))
+    assert torch.equal(wide[:, 2 : 2 + n2], new) and float((wide[:, :2] - 7.0).abs().max()) == 0.0
+    assert float((wide[:, 2 + n2 :] - 7.0).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("n", [1, 255, 4097, 300000])
 @pytest.mark.parametrize("k1,k2", [(1, 1), (2, 3), (4, 4), (3, 1)])
 def test_gram_small_block_inner_products(be, prec, n, k1, k2):
